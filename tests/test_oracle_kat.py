@@ -1,0 +1,299 @@
+"""Analytic known-answer tests that anchor the CPU oracle (SURVEY.md §8c list, items 1-9).
+
+The reference ships no golden vectors, so the oracle is pinned by identities that follow from the
+cited reference code alone.  CPU-only; runs in seconds.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+from util import orc, random_gauge_lex, random_spinor_lex, random_su3, unit_gauge_lex, gauge_eo_single_domain, \
+    sigmas, momenta_p2_le, rel_err
+
+LATTICES = [(4, 4, 4, 4), (4, 4, 4, 8), (6, 4, 8, 2)]
+
+
+# ---- (1) gamma-table self-consistency ---------------------------------------------------------
+def test_gamma_tables_are_ordered_products():
+    g = [orc.gamma_dense(n) for n in (1, 2, 4, 8)]          # g1, g2, g3, g4
+    for n in range(16):
+        prod = np.eye(4, dtype=complex)
+        for b in range(4):
+            if (n >> b) & 1:
+                prod = prod @ g[b]
+        assert np.array_equal(orc.gamma_dense(n), prod), n
+
+
+def test_gamma_clifford_hermitian_g5():
+    g = [orc.gamma_dense(n) for n in (1, 2, 4, 8)]
+    for mu in range(4):
+        assert np.array_equal(g[mu], g[mu].conj().T)
+        for nu in range(4):
+            anti = g[mu] @ g[nu] + g[nu] @ g[mu]
+            assert np.array_equal(anti, 2.0 * np.eye(4) * (mu == nu))
+    assert np.array_equal(orc.gamma_dense(15), np.diag([1, 1, -1, -1]).astype(complex))
+
+
+# ---- (2) gamma5 map ---------------------------------------------------------------------------
+def test_gamma5_map_matches_names():
+    g5 = orc.gamma_dense(15)
+    sign = orc.gamma_map_sign()
+    for ig in range(16):
+        j = orc.INDEX_MAP_GAMMA[ig]
+        assert j == 15 - ig
+        lhs = g5 @ orc.gamma_dense(j)
+        if ig in (1, 4):       # deliberate: output slots 14 / 11 are named g5g1 / g5g3 = -g5*G(14), -g5*G(11)
+            assert np.array_equal(lhs, -orc.gamma_dense(ig)) and sign[ig] == 1.0
+        else:
+            assert np.array_equal(lhs, sign[ig] * orc.gamma_dense(ig)), ig
+    assert orc.GAMMA_NAMES[14] == "g5g1" and orc.GAMMA_NAMES[11] == "g5g3"
+
+
+# ---- (9) even-odd round trip -------------------------------------------------------------------
+@pytest.mark.parametrize("X", LATTICES)
+def test_even_odd_round_trip(X):
+    vcb = int(np.prod(X)) // 2
+    seen = set()
+    for pty in range(2):
+        c = orc.get_coords(np.arange(vcb), X, pty)
+        assert np.all((c.sum(axis=1) & 1) == pty)
+        assert np.array_equal(orc.link_index(c, X), np.arange(vcb))
+        for row in c:
+            seen.add(tuple(row))
+        assert np.all(c >= 0) and np.all(c < np.asarray(X))
+    assert len(seen) == 2 * vcb
+    f = np.arange(int(np.prod(X))).reshape(X[3], X[2], X[1], X[0])
+    assert np.array_equal(orc.eo_to_lex(orc.lex_to_eo(f, X), X), f)
+
+
+@pytest.mark.parametrize("order", [orc.FLOAT2, orc.FLOAT4])
+def test_native_spinor_layout_round_trip(order):
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal((2, 32, 4, 3)) + 1j * rng.standard_normal((2, 32, 4, 3))
+    for stride in (32, 40):
+        buf = orc.spinor_to_native(v, order, stride=stride)
+        assert np.array_equal(orc.spinor_from_native(buf, order, 32, stride=stride), v)
+    # FLOAT4: two consecutive complex (k, k+1) of one site are adjacent in memory
+    if order == orc.FLOAT4:
+        assert orc.spinor_native_index(order, 0, 7, 0, 1, 32, 384) == orc.spinor_native_index(order, 0, 7, 0, 0, 32, 384) + 1
+
+
+# ---- (3)+(4) contraction ------------------------------------------------------------------------
+def test_contraction_unit_gamma_and_dense_gamma():
+    X = (4, 4, 4, 4)
+    rng = np.random.default_rng(11)
+    nev = 3
+    evL = [orc.lex_to_eo(random_spinor_lex(rng, X), X) for _ in range(nev)]
+    evR = [orc.lex_to_eo(random_spinor_lex(rng, X), X) for _ in range(nev)]
+    sg = sigmas(nev)
+    V = int(np.prod(X))
+    loop = np.zeros(16 * V, dtype=complex)
+    for n in range(nev):
+        orc.loop_contract(loop, evL[n], evR[n], sg[n])
+    # dense check: loop[x, iG] = sum_n sigma_n^-1 vL^dag(x) G(iG) vR(x)   (colour traced)
+    for iG in range(16):
+        G = orc.gamma_dense(iG)
+        ref = np.zeros(V, dtype=complex)
+        for n in range(nev):
+            L = evL[n].reshape(V, 4, 3)
+            R = evR[n].reshape(V, 4, 3)
+            ref += np.einsum("xbc,ba,xac->x", L.conj(), G, R) / sg[n]
+        assert rel_err(loop[V * iG:V * (iG + 1)], ref) < 1e-14
+    # Gamma = 1 slot with L == R: sum_x loop = sum_n ||v_n||^2 / sigma_n = sum_n 1/sigma_n
+    loop1 = np.zeros(16 * V, dtype=complex)
+    for n in range(nev):
+        orc.loop_contract(loop1, evL[n], evL[n], sg[n])
+    assert abs(loop1[:V].sum() - np.sum(1.0 / sg)) < 1e-10 * np.sum(1.0 / sg)
+    assert np.max(np.abs(loop1[:V].imag)) < 1e-16 * np.max(np.abs(loop1[:V].real)) + 1e-30
+
+
+# ---- (4)+(7) unit gauge: displacement is a pure shift; L_mu steps wrap around --------------------
+@pytest.mark.parametrize("X", LATTICES)
+def test_unit_gauge_displacement_is_shift_and_wraps(X):
+    rng = np.random.default_rng(3)
+    psi_lex = random_spinor_lex(rng, X)
+    psi = orc.lex_to_eo(psi_lex, X)
+    U = gauge_eo_single_domain(unit_gauge_lex(X), X)
+    axis_of_dir = {0: 3, 1: 2, 2: 1, 3: 0}                 # lex array is [T, Z, Y, X]
+    for dirn in range(4):
+        for sign in (orc.DISP_SIGN_PLUS, orc.DISP_SIGN_MINUS):
+            out = orc.covariant_displacement(psi, U, dirn, sign, X)
+            shift = -1 if sign == orc.DISP_SIGN_PLUS else 1   # dst(x) = src(x + mu) for sign +
+            expect = np.roll(psi_lex, shift, axis=axis_of_dir[dirn])
+            assert np.array_equal(orc.eo_to_lex(out, X), expect)
+            cur = psi
+            for _ in range(X[dirn]):
+                cur = orc.covariant_displacement(cur, U, dirn, sign, X)
+            assert np.array_equal(cur, psi)
+
+
+# ---- (5) D_-mu D_+mu = 1 -------------------------------------------------------------------------
+def test_forward_backward_displacement_is_identity():
+    X = (4, 4, 4, 8)
+    rng = np.random.default_rng(7)
+    psi = orc.lex_to_eo(random_spinor_lex(rng, X), X)
+    U = gauge_eo_single_domain(random_gauge_lex(rng, X), X)
+    for dirn in range(4):
+        fwd = orc.covariant_displacement(psi, U, dirn, orc.DISP_SIGN_PLUS, X)
+        back = orc.covariant_displacement(fwd, U, dirn, orc.DISP_SIGN_MINUS, X)
+        assert rel_err(back, psi) < 1e-12
+        bwd = orc.covariant_displacement(psi, U, dirn, orc.DISP_SIGN_MINUS, X)
+        back = orc.covariant_displacement(bwd, U, dirn, orc.DISP_SIGN_PLUS, X)
+        assert rel_err(back, psi) < 1e-12
+
+
+# ---- explicit formula check in lexicographic coordinates -----------------------------------------
+def test_displacement_matches_lexicographic_formula():
+    X = (4, 6, 4, 2)
+    rng = np.random.default_rng(17)
+    psi_lex = random_spinor_lex(rng, X)
+    U_lex = random_gauge_lex(rng, X)
+    psi = orc.lex_to_eo(psi_lex, X)
+    U = gauge_eo_single_domain(U_lex, X)
+    axis_of_dir = {0: 3, 1: 2, 2: 1, 3: 0}
+    for dirn in range(4):
+        ax = axis_of_dir[dirn]
+        # +: U_mu(x) psi(x+mu)
+        exp = np.einsum("tzyxab,tzyxsb->tzyxsa", U_lex[dirn], np.roll(psi_lex, -1, axis=ax))
+        got = orc.eo_to_lex(orc.covariant_displacement(psi, U, dirn, orc.DISP_SIGN_PLUS, X), X)
+        assert rel_err(got, exp) < 1e-15
+        # -: U_mu^dag(x-mu) psi(x-mu)
+        Ub = np.roll(U_lex[dirn], 1, axis=ax)
+        exp = np.einsum("tzyxba,tzyxsb->tzyxsa", Ub.conj(), np.roll(psi_lex, 1, axis=ax))
+        got = orc.eo_to_lex(orc.covariant_displacement(psi, U, dirn, orc.DISP_SIGN_MINUS, X), X)
+        assert rel_err(got, exp) < 1e-15
+
+
+# ---- (6) gauge covariance of displaced loops -------------------------------------------------------
+def test_displaced_loop_is_gauge_invariant():
+    X = (4, 4, 4, 4)
+    rng = np.random.default_rng(23)
+    nev = 2
+    ev_lex = [random_spinor_lex(rng, X) for _ in range(nev)]
+    U_lex = random_gauge_lex(rng, X)
+    g = random_su3(rng, (X[3], X[2], X[1], X[0]))
+    axis_of_dir = {0: 3, 1: 2, 2: 1, 3: 0}
+    Ug = np.stack([np.einsum("tzyxab,tzyxbc,tzyxdc->tzyxad", g, U_lex[mu],
+                             np.roll(g, -1, axis=axis_of_dir[mu]).conj()) for mu in range(4)])
+    evg = [np.einsum("tzyxab,tzyxsb->tzyxsa", g, v) for v in ev_lex]
+    cprm = orc.LoopComputeParam(["+x", "-y", "+t", "-z"], [1, 1, 2, 1], [2, 1, 3, 3])
+    assert cprm.nLoop == 1 + 2 + 1 + 2 + 3 and cprm.nLoopOffset == [1, 3, 4, 6]
+    a = orc.compute_loop_position_space([orc.lex_to_eo(v, X) for v in ev_lex], sigmas(nev), cprm,
+                                        gauge_eo_single_domain(U_lex, X), X)
+    b = orc.compute_loop_position_space([orc.lex_to_eo(v, X) for v in evg], sigmas(nev), cprm,
+                                        gauge_eo_single_domain(Ug, X), X)
+    assert rel_err(b, a) < 1e-13
+
+
+# ---- (8) FT: phase matrix + projection vs direct DFT ------------------------------------------------
+def test_phase_matrix_and_projection_vs_direct_dft():
+    X = (4, 6, 4, 8)
+    rng = np.random.default_rng(29)
+    V = int(np.prod(X))
+    vcb = V // 2
+    nLoop = 2
+    nData = 16 * nLoop
+    dataPos = rng.standard_normal(nData * V) + 1j * rng.standard_normal(nData * V)
+    moms = momenta_p2_le(2)
+    locV3 = X[0] * X[1] * X[2]
+    for FTSign in (+1, -1):
+        ph = orc.phase_matrix(moms, locV3, FTSign, X, X)
+        mp = orc.convert_idx_order_map_gamma(dataPos, nData, nLoop, 2, vcb, X)
+        mom = orc.momentum_projection_local(mp, ph, X[3], nData, locV3, len(moms))
+        mom = mom.reshape(len(moms), nLoop, 16, X[3])
+        # direct: lexicographic data, sum over x,y,z with exp(i FTSign 2pi p.x/L)
+        sign = orc.gamma_map_sign()
+        lex = np.stack([orc.eo_to_lex(dataPos[V * i:V * (i + 1)].reshape(2, vcb), X) for i in range(nData)])
+        xs, ys, zs = np.arange(X[0]), np.arange(X[1]), np.arange(X[2])
+        for im, p in enumerate(moms):
+            phase = np.exp(1j * FTSign * 2 * np.pi * (p[2] * zs[:, None, None] / X[2] + p[1] * ys[None, :, None] / X[1]
+                                                       + p[0] * xs[None, None, :] / X[0]))
+            direct = np.einsum("itzyx,zyx->it", lex, phase)        # [idata, t]
+            for iL in range(nLoop):
+                for ig in range(16):
+                    exp = sign[ig] * direct[ig + 16 * iL]
+                    assert rel_err(mom[im, iL, 15 - ig], exp) < 1e-12
+    # p = 0 is the plain spatial sum
+    ph0 = orc.phase_matrix([(0, 0, 0)], locV3, 1, X, X)
+    assert np.array_equal(ph0, np.ones(locV3, dtype=complex))
+
+
+# ---- multi-domain == single-domain ---------------------------------------------------------------------
+def _emulated_multi_domain_loop(ev_lex, U_lex, sg, cprm, G, grid):
+    ranks = list(itertools.product(*[range(g) for g in grid]))          # (cx, cy, cz, ct)
+    l = [G[d] // grid[d] for d in range(4)]
+    comm_dim = [1 if grid[d] > 1 else 0 for d in range(4)]
+    brd = [2 * c for c in comm_dim]                                      # lib/displace.cpp:16
+    V = int(np.prod(l))
+    perLoop = 16 * V
+    Uloc = {r: orc.extended_gauge_from_global(U_lex, r, grid, brd) for r in ranks}
+    data = {r: np.zeros(perLoop * cprm.nLoop, dtype=complex) for r in ranks}
+
+    def nbr(r, d, s):
+        q = list(r)
+        q[d] = (q[d] + s) % grid[d]
+        return tuple(q)
+
+    for idx in range(-1, cprm.nDispEntries):
+        for n, v_lex in enumerate(ev_lex):
+            vL = {r: orc.lex_to_eo(orc.local_block(v_lex, r, grid), l) for r in ranks}
+            if idx < 0:
+                for r in ranks:
+                    orc.loop_contract(data[r][:perLoop], vL[r], vL[r], sg[n])
+                continue
+            dirn, sign = orc.parse_displacement(cprm.dispString[idx])
+            off = perLoop * cprm.nLoopOffset[idx]
+            vR = {r: vL[r].copy() for r in ranks}
+            cnt = 0
+            for idisp in range(1, cprm.dispStop[idx] + 1):
+                ghost = {}
+                for r in ranks:                                           # exchangeGhostVec, all dims, both dirs
+                    gh = [[None, None] for _ in range(4)]
+                    for d in range(4):
+                        if comm_dim[d]:
+                            gh[d][1] = orc.pack_face(vR[nbr(r, d, +1)], l, d, high=0)
+                            gh[d][0] = orc.pack_face(vR[nbr(r, d, -1)], l, d, high=1)
+                    ghost[r] = gh
+                vR = {r: orc.covariant_displacement(vR[r], Uloc[r], dirn, sign, l, comm_dim, brd, ghost[r])
+                      for r in ranks}
+                if cprm.dispStart[idx] <= idisp <= cprm.dispStop[idx]:
+                    for r in ranks:
+                        s0 = off + perLoop * cnt
+                        orc.loop_contract(data[r][s0:s0 + perLoop], vL[r], vR[r], sg[n])
+                    cnt += 1
+    return data, l
+
+
+@pytest.mark.parametrize("grid", [(1, 1, 1, 2), (1, 1, 2, 2), (2, 1, 1, 1), (1, 2, 1, 1)])
+def test_multi_domain_equals_single_domain(grid):
+    G = (4, 4, 4, 8)
+    rng = np.random.default_rng(31)
+    nev = 2
+    ev_lex = [random_spinor_lex(rng, G) for _ in range(nev)]
+    U_lex = random_gauge_lex(rng, G)
+    sg = sigmas(nev)
+    cprm = orc.LoopComputeParam(["+t", "-t", "+z", "-z", "+x", "-y"], [1, 1, 1, 2, 1, 1], [2, 1, 1, 2, 1, 2])
+    single = orc.compute_loop_position_space([orc.lex_to_eo(v, G) for v in ev_lex], sg, cprm,
+                                             gauge_eo_single_domain(U_lex, G), G)
+    Vg = int(np.prod(G))
+    data, l = _emulated_multi_domain_loop(ev_lex, U_lex, sg, cprm, G, grid)
+    Vl = int(np.prod(l))
+    for r, d in data.items():
+        for idata in range(cprm.nData):
+            glob = orc.eo_to_lex(single[Vg * idata:Vg * (idata + 1)].reshape(2, Vg // 2), G)
+            loc = orc.eo_to_lex(d[Vl * idata:Vl * (idata + 1)].reshape(2, Vl // 2), l)
+            assert rel_err(loc, orc.local_block(glob, r, grid)) < 1e-14
+
+
+def test_parse_displacement_strings_and_bookkeeping():
+    assert orc.parse_displacement("+x") == (0, orc.DISP_SIGN_PLUS)
+    assert orc.parse_displacement("-t") == (3, orc.DISP_SIGN_MINUS)
+    with pytest.raises(ValueError):
+        orc.parse_displacement("+w")
+    e, s, a, b = orc.parse_disp_entry_string("+z:1,8;-x:3;+y:5,2")
+    assert s == ["+z", "-x", "+y"] and a == [1, 3, 5] and b == [8, 3, 2]
+    c = orc.LoopComputeParam(s, a, b)
+    assert c.dispStart == [1, 3, 2] and c.dispStop == [8, 3, 5]       # start > stop are swapped
+    assert c.nLoopPerEntry == [8, 1, 4] and c.nLoopOffset == [1, 9, 10] and c.nLoop == 14 and c.nData == 224
+    assert orc.LoopComputeParam(doNonLocal=False).nLoop == 1
