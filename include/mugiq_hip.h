@@ -1,0 +1,178 @@
+/*
+ * mugiq_hip.h -- C ABI of libmugiq_hip.so, the MI355X-native (HIP / gfx950) drop-in for the
+ * disconnected-loop hot path of ckallidonis/mugiq.
+ *
+ * Every entry point names the reference interface it replaces (file:line, relative to the MuGiq tree).
+ * The reference's operator API is a set of C++ templates over QUDA types
+ * (lib/contract_wrappers.cu, declared at include/loop_mugiq.h:280-311 and include/displace.h:109-111);
+ * QUDA types cannot cross a C ABI, so each function takes plain pointers plus the POD descriptors below,
+ * which carry exactly what the reference's Arg structs read out of a ColorSpinorField / cudaGaugeField
+ * (include/contract_util.cuh:69-194).  include/mugiq_hip_operators.hpp re-declares the reference's
+ * template names on top of this ABI; INTEGRATION.md shows the QUDA-side adapter.
+ *
+ * Conventions
+ *  - all data pointers are DEVICE pointers unless the parameter name ends in _h;
+ *  - every function returns 0 on success and a non-zero MugiqHipStatus on failure; the message is
+ *    available from mugiq_hip_last_error() (the reference aborts through errorQuda instead:
+ *    lib/contract_wrappers.cu:100,138,185);
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls are asynchronous on
+ *    that stream; nothing in this library calls hipDeviceSynchronize on the data path;
+ *  - the caller owns every buffer.  Loop buffers are ACCUMULATED into (+=) and must be zeroed by the
+ *    caller, as in the reference (lib/loop_mugiq.cpp:138,476).
+ */
+#ifndef MUGIQ_HIP_H
+#define MUGIQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUGIQ_HIP_VERSION 100
+
+typedef enum MugiqHipStatus_e {
+  MUGIQ_HIP_SUCCESS = 0,
+  MUGIQ_HIP_ERROR_INVALID_ARGUMENT = 1, /* precondition the reference checks with errorQuda */
+  MUGIQ_HIP_ERROR_UNSUPPORTED = 2,
+  MUGIQ_HIP_ERROR_HIP = 3,              /* a HIP runtime call failed (reference: checkCudaError) */
+  MUGIQ_HIP_ERROR_NO_DEVICE = 4
+} MugiqHipStatus;
+
+/* Values are those of QudaPrecision / QudaFieldOrder so an adapter can pass them through. */
+#define MUGIQ_HIP_SINGLE_PRECISION 4
+#define MUGIQ_HIP_DOUBLE_PRECISION 8
+#define MUGIQ_HIP_FLOAT2_FIELD_ORDER 2
+#define MUGIQ_HIP_FLOAT4_FIELD_ORDER 4
+
+/* include/enum_mugiq.h:72-85 */
+#define MUGIQ_HIP_DISP_DIR_X 0
+#define MUGIQ_HIP_DISP_DIR_Y 1
+#define MUGIQ_HIP_DISP_DIR_Z 2
+#define MUGIQ_HIP_DISP_DIR_T 3
+#define MUGIQ_HIP_DISP_SIGN_MINUS 0
+#define MUGIQ_HIP_DISP_SIGN_PLUS 1
+
+/*
+ * A nSpin=4, nColor=3 colour-spinor field in QUDA's native even-odd layout: what
+ * colorspinor::FieldOrderCB<Float,4,3,1,order> (include/contract_util.cuh:20-21) addresses.
+ * Complex-element index of component k = 3*spin + colour at (parity, x_cb):
+ *   FLOAT2: parity*parity_offset + k*stride + x_cb
+ *   FLOAT4: parity*parity_offset + ((k/2)*stride + x_cb)*2 + (k%2)
+ * ghost[dim][0|1] are the backward / forward ghost zones filled by a halo exchange of depth 1
+ * (reference: ColorSpinorField::exchangeGhost, lib/contract_wrappers.cu:166-169); each zone is itself
+ * laid out like a field body with volumeCB = stride = faceCB(dim), parity_offset = 12*faceCB(dim),
+ * indexed by QUDA's ghostFaceIndex.  They are read only for partitioned dims (commDim[dim] != 0).
+ */
+typedef struct MugiqHipSpinorField_s {
+  void *data;            /* ColorSpinorField::V() */
+  int precision;         /* 4 | 8 */
+  int field_order;       /* 2 | 4 */
+  int nParity;           /* SiteSubset(); the hot path requires 2 (lib/contract_wrappers.cu:100,185) */
+  int volumeCB;          /* VolumeCB() */
+  int stride;            /* Stride() = volumeCB + pad */
+  int X[4];              /* full local lattice dims (x,y,z,t), all even */
+  int64_t parity_offset; /* complex elements between the two parities = Bytes()/2/sizeof(complex) */
+  void *ghost[4][2];     /* may be all NULL on a single domain */
+} MugiqHipSpinorField;
+
+/*
+ * The border-extended gauge field Displace builds (lib/displace.cpp:104-134), in QUDA's native
+ * FLOAT2 gauge order with 18 reals per link (gauge_mapper<Float,QUDA_RECONSTRUCT_NO>,
+ * include/contract_util.cuh:23-24): complex index of element (row,col) of link (dir, x_cb, parity)
+ *   parity*parity_offset + (dir*9 + row*3 + col)*stride + x_cb
+ * with x_cb the even-odd index on the EXTENDED lattice dimEx = X + 2*R.
+ */
+typedef struct MugiqHipGaugeField_s {
+  void *data;
+  int precision;         /* 4 | 8 */
+  int X[4];              /* interior (non-extended) local dims */
+  int R[4];              /* border per dim; reference uses 2*commDimPartitioned (lib/displace.cpp:16) */
+  int stride;            /* extended volumeCB + pad */
+  int64_t parity_offset; /* complex elements between parities */
+} MugiqHipGaugeField;
+
+/* ---- housekeeping ------------------------------------------------------------------------------- */
+int mugiq_hip_version(void);
+const char *mugiq_hip_last_error(void);
+/* number of visible HIP devices (0 if none); does not initialise a context */
+int mugiq_hip_device_count(void);
+
+/* ---- gamma tables ------------------------------------------------------------------------------- */
+/* copyGammaCoeffStructToSymbol<Float>()  lib/contract_wrappers.cu:6-19
+ * copyGammaMapStructToSymbol<Float>()    lib/contract_wrappers.cu:26-43
+ * The tables are compile-time constants of the HIP kernels, so these only validate `precision`;
+ * they are kept so Loop_Mugiq::copyGammaToConstMem (lib/loop_mugiq.cpp:162-167) maps 1:1. */
+int mugiq_hip_copy_gamma_coeff_to_symbol(int precision);
+int mugiq_hip_copy_gamma_map_to_symbol(int precision);
+/* Host copies of the tables the kernels were compiled with (include/gamma.h:32-71,99-109):
+ * row_value[16][4][2] (re,im), column_index[16][4], map_sign[16], map_index[16]. Any pointer may be NULL. */
+int mugiq_hip_get_gamma_tables(double *row_value_h, int *column_index_h, double *map_sign_h, int *map_index_h);
+/* GammaName(m)  include/gamma.h:11-20 ; NULL if m is out of range */
+const char *mugiq_hip_gamma_name(int m);
+
+/* ---- a1/a2  ultra-local or displaced loop contraction ------------------------------------------------ */
+/* performLoopContraction<Float,order>(loopData_d, eVecL, eVecR, sigma)   lib/contract_wrappers.cu:88-115
+ * kernel loopContract_kernel lib/mugiq_contract_kernels.cu:45-122:
+ *   loopData[tid + V*iG] += (1/sigma) * vL^dag(x) G(iG) vR(x),  tid = x_cb + parity*volumeCB, iG in [0,16)
+ * loopData_d: complex<Float>[16*V] of the fields' precision. */
+int mugiq_hip_perform_loop_contraction(void *loopData_d, const MugiqHipSpinorField *eVecL,
+                                       const MugiqHipSpinorField *eVecR, double sigma, void *stream);
+
+/* The fast path (new): the eigenvector loop of Loop_Mugiq::computeCoarseLoop (lib/loop_mugiq.cpp:478-503)
+ * folded into one launch: loopData += sum_{n<nVec} (1/sigma[n]) vL_n^dag G vR_n with the 16 accumulators
+ * held in registers, so each eigenvector is read once and loopData is touched once.
+ * eVecL_h/eVecR_h: host arrays of nVec descriptors (same geometry, precision, order); sigma_h: host doubles
+ * (eVals_sigma, cast to Float as at lib/loop_mugiq.cpp:479).  eVecR_h may equal eVecL_h (ultra-local). */
+int mugiq_hip_perform_loop_contraction_batched(void *loopData_d, const MugiqHipSpinorField *eVecL_h,
+                                               const MugiqHipSpinorField *eVecR_h, const double *sigma_h,
+                                               int nVec, void *stream);
+
+/* ---- a4/a5  covariant displacement --------------------------------------------------------------------- */
+/* performCovariantDisplacementVector<Float,order>(dst, src, gauge, dispDir, dispSign)
+ * lib/contract_wrappers.cu:171-198, kernel lib/mugiq_displace_kernels.cu:156-185:
+ *   dst(x) = U_d(x) src(x+d)  (sign +)   |   dst(x) = U_d^dag(x-d) src(x-d)  (sign -)
+ * commDim[4] replaces QUDA's global comm_dim_partitioned() (include/contract_util.cuh:89): for a
+ * partitioned dim the neighbour of an on-face site is read from src->ghost[dim][bnd].  The halo
+ * exchange itself (exchangeGhostVec, :166-169) is the caller's job -- see mugiq_hip_pack_face. */
+int mugiq_hip_perform_covariant_displacement_vector(const MugiqHipSpinorField *dst,
+                                                    const MugiqHipSpinorField *src,
+                                                    const MugiqHipGaugeField *gauge, int dispDir,
+                                                    int dispSign, const int commDim[4], void *stream);
+
+/* Pack the face of `src` a neighbour needs as its depth-1 ghost zone, in ghostFaceIndex order
+ * (the send half of ColorSpinorField::exchangeGhost, lib/contract_wrappers.cu:166-169).
+ *   high = 0: low face  (x[dim] = 0)        -> the backward neighbour's ghost[dim][1]
+ *   high = 1: high face (x[dim] = X[dim]-1) -> the forward  neighbour's ghost[dim][0]
+ * face_d: 2*12*faceCB complex elements of the field's precision, laid out as a ghost zone. */
+int mugiq_hip_pack_face(void *face_d, const MugiqHipSpinorField *src, int dim, int high, void *stream);
+
+/* ---- a8  Fourier phase matrix -------------------------------------------------------------------------- */
+/* createPhaseMatrixGPU<Float>(phaseMatrix_d, momMatrix_h, locV3, Nmom, FTSign, localL, totalL)
+ * lib/contract_wrappers.cu:50-77, kernel lib/mugiq_util_kernels.cu:3-35.  commCoord[4] replaces QUDA's
+ * comm_coord() (include/contract_util.cuh:64).  momMatrix_h: int[Nmom][3], MOM_MATRIX_IDX(id,im)=id+3*im. */
+int mugiq_hip_create_phase_matrix(void *phaseMatrix_d, const int *momMatrix_h, long long locV3, int Nmom,
+                                  int FTSign, const int localL[4], const int totalL[4],
+                                  const int commCoord[4], int precision, void *stream);
+
+/* ---- a9  even-odd -> time-major reorder with the G -> g5 G map ------------------------------------------ */
+/* convertIdxOrder_mapGamma<Float>(dataPosMP_d, dataPos_d, nData, nLoop, nParity, volumeCB, localL)
+ * lib/contract_wrappers.cu:133-156, kernel lib/mugiq_util_kernels.cu:59-99 */
+int mugiq_hip_convert_idx_order_map_gamma(void *dataPosMP_d, const void *dataPos_d, int nData, int nLoop,
+                                          int nParity, int volumeCB, const int localL[4], int precision,
+                                          void *stream);
+
+/* ---- a10  momentum projection (the cublasZgemm/Cgemm of lib/loop_mugiq.cpp:363-378) ---------------------- */
+/* dataMom_d[M x N] = dataPosMP_d[M x K] * phaseMatrix_d[K x N], column-major, M = locT*nData, K = locV3,
+ * N = Nmom, alpha = 1, beta = 0.  workspace_d may be NULL (the library then allocates its own scratch);
+ * mugiq_hip_momentum_projection_workspace returns the bytes it would like. */
+size_t mugiq_hip_momentum_projection_workspace(int locT, int nData, long long locV3, int Nmom, int precision);
+int mugiq_hip_momentum_projection(void *dataMom_d, const void *dataPosMP_d, const void *phaseMatrix_d,
+                                  int locT, int nData, long long locV3, int Nmom, int precision,
+                                  void *workspace_d, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUGIQ_HIP_H */

@@ -1,0 +1,19 @@
+"""mugiq_amd -- MI355X-native (HIP / gfx950) drop-in for the disconnected-loop hot path of ckallidonis/mugiq.
+
+The product is libmugiq_hip.so (C ABI in include/mugiq_hip.h).  This package is the Python host-side mirror
+of MuGiq's operator interface over that ABI; importing it loads the library and fails loudly if it is missing.
+"""
+from . import _lib
+
+_lib.load()
+
+from .fields import SpinorField, GaugeField, FLOAT2, FLOAT4  # noqa: E402
+from .operators import (  # noqa: E402
+    copyGammaCoeffStructToSymbol, copyGammaMapStructToSymbol, gammaTables, GammaName,
+    performLoopContraction, performLoopContractionBatched, performCovariantDisplacementVector, packFace,
+    createPhaseMatrixGPU, convertIdxOrder_mapGamma, momentumProjection,
+    DispDir, DispSignMinus, DispSignPlus, LOOP_FT_SIGN_MINUS, LOOP_FT_SIGN_PLUS, DisplaceFlagArray,
+)
+from ._lib import MugiqHipError, LIB_PATH  # noqa: E402
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,97 @@
+"""ctypes loader for libmugiq_hip.so (built in-tree by `make -C mugiq_amd/csrc` / __graft_entry__.build()).
+
+There is NO fallback: if the HIP library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmugiq_hip.so")
+
+
+class MugiqHipError(RuntimeError):
+    """Raised for every non-zero status of the C ABI (the reference aborts through errorQuda)."""
+
+
+class SpinorDesc(ctypes.Structure):
+    """MugiqHipSpinorField (include/mugiq_hip.h)."""
+    _fields_ = [("data", ctypes.c_void_p),
+                ("precision", ctypes.c_int),
+                ("field_order", ctypes.c_int),
+                ("nParity", ctypes.c_int),
+                ("volumeCB", ctypes.c_int),
+                ("stride", ctypes.c_int),
+                ("X", ctypes.c_int * 4),
+                ("parity_offset", ctypes.c_int64),
+                ("ghost", (ctypes.c_void_p * 2) * 4)]
+
+
+class GaugeDesc(ctypes.Structure):
+    """MugiqHipGaugeField (include/mugiq_hip.h)."""
+    _fields_ = [("data", ctypes.c_void_p),
+                ("precision", ctypes.c_int),
+                ("X", ctypes.c_int * 4),
+                ("R", ctypes.c_int * 4),
+                ("stride", ctypes.c_int),
+                ("parity_offset", ctypes.c_int64)]
+
+
+_I4 = ctypes.POINTER(ctypes.c_int)
+_VP = ctypes.c_void_p
+_SP = ctypes.POINTER(SpinorDesc)
+_GP = ctypes.POINTER(GaugeDesc)
+
+# name -> (restype, argtypes); every symbol include/mugiq_hip.h declares
+SIGNATURES = {
+    "mugiq_hip_version": (ctypes.c_int, []),
+    "mugiq_hip_last_error": (ctypes.c_char_p, []),
+    "mugiq_hip_device_count": (ctypes.c_int, []),
+    "mugiq_hip_copy_gamma_coeff_to_symbol": (ctypes.c_int, [ctypes.c_int]),
+    "mugiq_hip_copy_gamma_map_to_symbol": (ctypes.c_int, [ctypes.c_int]),
+    "mugiq_hip_get_gamma_tables": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), _I4,
+                                                  ctypes.POINTER(ctypes.c_double), _I4]),
+    "mugiq_hip_gamma_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "mugiq_hip_perform_loop_contraction": (ctypes.c_int, [_VP, _SP, _SP, ctypes.c_double, _VP]),
+    "mugiq_hip_perform_loop_contraction_batched": (ctypes.c_int, [_VP, _SP, _SP, ctypes.POINTER(ctypes.c_double),
+                                                                  ctypes.c_int, _VP]),
+    "mugiq_hip_perform_covariant_displacement_vector": (ctypes.c_int, [_SP, _SP, _GP, ctypes.c_int, ctypes.c_int,
+                                                                       _I4, _VP]),
+    "mugiq_hip_pack_face": (ctypes.c_int, [_VP, _SP, ctypes.c_int, ctypes.c_int, _VP]),
+    "mugiq_hip_create_phase_matrix": (ctypes.c_int, [_VP, _I4, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+                                                     _I4, _I4, _I4, ctypes.c_int, _VP]),
+    "mugiq_hip_convert_idx_order_map_gamma": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                             ctypes.c_int, _I4, ctypes.c_int, _VP]),
+    "mugiq_hip_momentum_projection_workspace": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_longlong,
+                                                                  ctypes.c_int, ctypes.c_int]),
+    "mugiq_hip_momentum_projection": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_longlong,
+                                                     ctypes.c_int, ctypes.c_int, _VP, ctypes.c_size_t, _VP]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise (never fall back) if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `make -C mugiq_amd/csrc` or "
+                          "`python -c 'import __graft_entry__ as g; g.build()'` -- there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        msg = load().mugiq_hip_last_error()
+        raise MugiqHipError("status %d: %s" % (status, msg.decode() if msg else "?"))
+
+
+def int4(v):
+    return (ctypes.c_int * 4)(*[int(x) for x in v])

@@ -1,0 +1,223 @@
+// a1/a2: 16-gamma loop contraction, eigenvector-batched.
+//
+// Reference: loopContract_kernel (lib/mugiq_contract_kernels.cu:45-122) launched once per eigenvector by
+// performLoopContraction (lib/contract_wrappers.cu:88-115) with a (16,2,16) block, LDS staging done by
+// one z-thread in 16 and a global read-modify-write of the 16-gamma accumulator per eigenvector.
+//
+// MI355X design: one lattice site per lane, sites coalesced over the even-odd index (each of the 12
+// FLOAT2 planes is read as one 1 KiB request per wave), the eigenvector loop INSIDE the kernel.  Because
+// the gamma trace is linear, the per-eigenvector work is only the colour-traced spin matrix
+//   resG[be][al] += (1/sigma_n) * sum_c conj(vL_n[be,c]) * vR_n[al,c]           (:98-105)
+// held in registers; the 16 sparse gamma traces (:110-117) are taken once after the loop and added to
+// loopData (:120).  HBM traffic is the algorithmic minimum: 24*sizeof(F) per site per eigenvector
+// (12 complex, once) plus one read+write of the 16 outputs.  When vL == vR (ultra-local loop) resG is
+// Hermitian and only its upper triangle is accumulated.
+#include "internal.h"
+
+#include <vector>
+
+namespace mugiq {
+
+constexpr int kContractBlock = 256;
+
+template <typename F> struct ContractArgs {
+  Cplx<F> *loop;           // [16][V]
+  const void *const *L;    // device table: nVec field bodies
+  const void *const *R;    // device table (unused when SAME)
+  const F *inv_sigma;      // device [nVec]
+  int nVec;
+  int volumeCB;
+  int stride;
+  int64_t parity_offset;
+};
+
+// acc (full 4x4) += conj(l[be,c]) * (s * r[al,c])
+template <typename F> __device__ inline void accumulate_full(Cplx<F> acc[16], const Cplx<F> l[12], const Cplx<F> r[12], F s) {
+  Cplx<F> sr[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) sr[k] = Cplx<F>{s * r[k].re, s * r[k].im};
+#pragma unroll
+  for (int be = 0; be < 4; be++)
+#pragma unroll
+    for (int al = 0; al < 4; al++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) cmadd_conj(acc[be * 4 + al], l[be * 3 + c], sr[al * 3 + c]);
+}
+
+// Hermitian case (l == r): diagonal kept in diag[4] (real), strict upper triangle in up[6]
+// pair order (be,al): (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+template <typename F> __device__ inline void accumulate_herm(F diag[4], Cplx<F> up[6], const Cplx<F> v[12], F s) {
+  Cplx<F> sv[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) sv[k] = Cplx<F>{s * v[k].re, s * v[k].im};
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      diag[a] = fma(v[a * 3 + c].re, sv[a * 3 + c].re, diag[a]);
+      diag[a] = fma(v[a * 3 + c].im, sv[a * 3 + c].im, diag[a]);
+    }
+  int p = 0;
+#pragma unroll
+  for (int be = 0; be < 4; be++)
+#pragma unroll
+    for (int al = be + 1; al < 4; al++) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) cmadd_conj(up[p], v[be * 3 + c], sv[al * 3 + c]);
+      p++;
+    }
+}
+
+template <typename F, int ORDER, bool SAME>
+__global__ __launch_bounds__(kContractBlock) void loop_contract_kernel(ContractArgs<F> a) {
+  const int V = 2 * a.volumeCB;
+  const int site = blockIdx.x * kContractBlock + threadIdx.x;  // tid = x_cb + parity*volumeCB  (:52)
+  if (site >= V) return;
+  const int parity = site >= a.volumeCB ? 1 : 0;
+  const int x_cb = site - parity * a.volumeCB;
+
+  Cplx<F> acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = Cplx<F>{F(0), F(0)};
+
+  auto view = [&](const void *const *tab, int n) {
+    return SpinorView<F, ORDER>{const_cast<F *>(static_cast<const F *>(tab[n])), a.stride, a.parity_offset};
+  };
+
+  if constexpr (SAME) {
+    F diag[4] = {F(0), F(0), F(0), F(0)};
+    Cplx<F> up[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) up[i] = Cplx<F>{F(0), F(0)};
+    Cplx<F> vA[12], vB[12];
+    int n = 0;
+    view(a.L, 0).load(vA, parity, x_cb);
+    for (; n + 1 < a.nVec; n += 2) {  // two eigenvectors per trip: the next load is in flight while one is consumed
+      view(a.L, n + 1).load(vB, parity, x_cb);
+      accumulate_herm(diag, up, vA, a.inv_sigma[n]);
+      if (n + 2 < a.nVec) view(a.L, n + 2).load(vA, parity, x_cb);
+      accumulate_herm(diag, up, vB, a.inv_sigma[n + 1]);
+    }
+    if (n < a.nVec) accumulate_herm(diag, up, vA, a.inv_sigma[n]);
+    int p = 0;
+#pragma unroll
+    for (int be = 0; be < 4; be++) {
+      acc[be * 4 + be] = Cplx<F>{diag[be], F(0)};
+#pragma unroll
+      for (int al = be + 1; al < 4; al++) {
+        acc[be * 4 + al] = up[p];
+        acc[al * 4 + be] = Cplx<F>{up[p].re, -up[p].im};
+        p++;
+      }
+    }
+  } else {
+    Cplx<F> lA[12], rA[12], lB[12], rB[12];
+    int n = 0;
+    view(a.L, 0).load(lA, parity, x_cb);
+    view(a.R, 0).load(rA, parity, x_cb);
+    for (; n + 1 < a.nVec; n += 2) {
+      view(a.L, n + 1).load(lB, parity, x_cb);
+      view(a.R, n + 1).load(rB, parity, x_cb);
+      accumulate_full(acc, lA, rA, a.inv_sigma[n]);
+      if (n + 2 < a.nVec) {
+        view(a.L, n + 2).load(lA, parity, x_cb);
+        view(a.R, n + 2).load(rA, parity, x_cb);
+      }
+      accumulate_full(acc, lB, rB, a.inv_sigma[n + 1]);
+    }
+    if (n < a.nVec) accumulate_full(acc, lA, rA, a.inv_sigma[n]);
+  }
+
+  // trace = sum_{s2} row_value[iG][s2] * resG[s2][column_index[iG][s2]]; loopData[tid + V*iG] += trace (:110-120)
+#pragma unroll
+  for (int iG = 0; iG < 16; iG++) {
+    Cplx<F> t{F(0), F(0)};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++) add_phase(t, kGammaPhase[iG][s2], acc[s2 * 4 + kGammaColumn[iG][s2]]);
+    Cplx<F> *out = a.loop + (int64_t)V * iG + site;
+    Cplx<F> o = *out;
+    o.re += t.re;
+    o.im += t.im;
+    *out = o;
+  }
+}
+
+template <typename F, int ORDER>
+static int launch_contract(void *loop_d, const MugiqHipSpinorField *L, const MugiqHipSpinorField *R, const double *sigma,
+                           int nVec, bool same, hipStream_t stream) {
+  // device tables: [L pointers][R pointers][inv_sigma]
+  const size_t ptr_bytes = sizeof(void *) * (size_t)nVec;
+  const size_t tab_bytes = 2 * ptr_bytes + sizeof(F) * (size_t)nVec;
+  std::vector<unsigned char> host(tab_bytes);
+  const void **hl = reinterpret_cast<const void **>(host.data());
+  const void **hr = reinterpret_cast<const void **>(host.data() + ptr_bytes);
+  F *hs = reinterpret_cast<F *>(host.data() + 2 * ptr_bytes);
+  for (int n = 0; n < nVec; n++) {
+    hl[n] = L[n].data;
+    hr[n] = R[n].data;
+    const F sg = static_cast<F>(sigma[n]);   // (Float) eVals_sigma[n]   lib/loop_mugiq.cpp:479
+    hs[n] = static_cast<F>(1.0 / sg);        // inv_sigma(1.0/sigma)     include/contract_util.cuh:132
+  }
+  void *dev = nullptr;
+  int st = upload_table(&dev, host.data(), tab_bytes, stream);
+  if (st) return st;
+
+  ContractArgs<F> a;
+  a.loop = static_cast<Cplx<F> *>(loop_d);
+  a.L = reinterpret_cast<const void *const *>(dev);
+  a.R = reinterpret_cast<const void *const *>(static_cast<unsigned char *>(dev) + ptr_bytes);
+  a.inv_sigma = reinterpret_cast<const F *>(static_cast<unsigned char *>(dev) + 2 * ptr_bytes);
+  a.nVec = nVec;
+  a.volumeCB = L[0].volumeCB;
+  a.stride = L[0].stride;
+  a.parity_offset = L[0].parity_offset;
+  const int V = 2 * a.volumeCB;
+  const dim3 grid((V + kContractBlock - 1) / kContractBlock), block(kContractBlock);
+  if (same)
+    hipLaunchKernelGGL((loop_contract_kernel<F, ORDER, true>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((loop_contract_kernel<F, ORDER, false>), grid, block, 0, stream, a);
+  MUGIQ_CHECK_HIP(hipGetLastError());
+  return MUGIQ_HIP_SUCCESS;
+}
+
+static int contract_dispatch(void *loop_d, const MugiqHipSpinorField *L, const MugiqHipSpinorField *R, const double *sigma,
+                             int nVec, void *stream, const char *who) {
+  MUGIQ_REQUIRE(loop_d != nullptr, "%s: loopData_d is NULL", who);
+  MUGIQ_REQUIRE(L != nullptr && R != nullptr && sigma != nullptr, "%s: NULL argument", who);
+  MUGIQ_REQUIRE(nVec >= 1, "%s: nVec = %d must be >= 1", who, nVec);
+  bool same = true;
+  for (int n = 0; n < nVec; n++) {
+    int st = validate_spinor(&L[n], who, "eVecL");
+    if (st) return st;
+    st = validate_spinor(&R[n], who, "eVecR");
+    if (st) return st;
+    MUGIQ_REQUIRE(same_geometry(L[n], L[0]) && same_geometry(R[n], L[0]),
+                  "%s: eigenvector %d differs in precision, field order or geometry from eigenvector 0", who, n);
+    MUGIQ_REQUIRE(sigma[n] != 0.0, "%s: sigma[%d] is zero", who, n);
+    same = same && (L[n].data == R[n].data);
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int prec = L[0].precision, order = L[0].field_order;
+  if (prec == 8 && order == 2) return launch_contract<double, 2>(loop_d, L, R, sigma, nVec, same, s);
+  if (prec == 8 && order == 4) return launch_contract<double, 4>(loop_d, L, R, sigma, nVec, same, s);
+  if (prec == 4 && order == 2) return launch_contract<float, 2>(loop_d, L, R, sigma, nVec, same, s);
+  return launch_contract<float, 4>(loop_d, L, R, sigma, nVec, same, s);
+}
+
+}  // namespace mugiq
+
+extern "C" {
+
+int mugiq_hip_perform_loop_contraction(void *loopData_d, const MugiqHipSpinorField *eVecL, const MugiqHipSpinorField *eVecR,
+                                       double sigma, void *stream) {
+  return mugiq::contract_dispatch(loopData_d, eVecL, eVecR, &sigma, 1, stream, "performLoopContraction");
+}
+
+int mugiq_hip_perform_loop_contraction_batched(void *loopData_d, const MugiqHipSpinorField *eVecL_h,
+                                               const MugiqHipSpinorField *eVecR_h, const double *sigma_h, int nVec,
+                                               void *stream) {
+  return mugiq::contract_dispatch(loopData_d, eVecL_h, eVecR_h, sigma_h, nVec, stream, "performLoopContractionBatched");
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+// Internal helpers shared by the HIP translation units of libmugiq_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "mugiq_hip.h"
+
+namespace mugiq {
+
+// ---- error plumbing ------------------------------------------------------------------------------
+int set_error(int status, const char *fmt, ...);
+#define MUGIQ_CHECK_HIP(call)                                                                     \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return ::mugiq::set_error(MUGIQ_HIP_ERROR_HIP, "%s:%d: %s failed: %s", __FILE__, __LINE__,  \
+                                #call, hipGetErrorString(e_));                                    \
+  } while (0)
+#define MUGIQ_REQUIRE(cond, ...)                                                                  \
+  do {                                                                                            \
+    if (!(cond)) return ::mugiq::set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, __VA_ARGS__);        \
+  } while (0)
+
+// Small device scratch for per-call tables (pointer lists, sigmas); grows on demand, per process.
+int device_scratch(void **ptr, size_t bytes);
+// Copy a small host table into the device scratch on `stream` (through a pinned staging buffer, so the
+// caller's memory may be released on return).  Tables of successive calls reuse the same scratch: calls
+// must be issued on one stream at a time per device (the reference's wrappers are not re-entrant either).
+int upload_table(void **dev, const void *host, size_t bytes, hipStream_t stream);
+
+// ---- complex arithmetic in registers -------------------------------------------------------------
+template <typename F> struct alignas(2 * sizeof(F)) Cplx {
+  F re, im;
+};
+template <typename F> __host__ __device__ inline Cplx<F> cmake(F re, F im) { return Cplx<F>{re, im}; }
+// a += conj(x) * y
+template <typename F> __device__ inline void cmadd_conj(Cplx<F> &a, const Cplx<F> &x, const Cplx<F> &y) {
+  a.re = fma(x.re, y.re, a.re);
+  a.re = fma(x.im, y.im, a.re);
+  a.im = fma(x.re, y.im, a.im);
+  a.im = fma(-x.im, y.re, a.im);
+}
+// a += x * y
+template <typename F> __device__ inline void cmadd(Cplx<F> &a, const Cplx<F> &x, const Cplx<F> &y) {
+  a.re = fma(x.re, y.re, a.re);
+  a.re = fma(-x.im, y.im, a.re);
+  a.im = fma(x.re, y.im, a.im);
+  a.im = fma(x.im, y.re, a.im);
+}
+
+// ---- DeGrand-Rossi gamma tables, include/gamma.h:32-71 of the reference ----------------------------
+// G(n)_{ij} = value[n][i] * delta(j, column[n][i]); value in {+1,-1,+i,-i} encoded as a power of i:
+// 0 -> +1, 1 -> +i, 2 -> -1, 3 -> -i.
+constexpr int kGammaPhase[16][4] = {
+    {0, 0, 0, 0}, {1, 1, 3, 3}, {2, 0, 0, 2}, {3, 1, 3, 1}, {1, 3, 3, 1}, {2, 0, 2, 0}, {3, 3, 3, 3}, {0, 0, 2, 2},
+    {0, 0, 0, 0}, {1, 1, 3, 3}, {2, 0, 0, 2}, {3, 1, 3, 1}, {1, 3, 3, 1}, {2, 0, 2, 0}, {3, 3, 3, 3}, {0, 0, 2, 2}};
+constexpr int kGammaColumn[16][4] = {
+    {0, 1, 2, 3}, {3, 2, 1, 0}, {3, 2, 1, 0}, {0, 1, 2, 3}, {2, 3, 0, 1}, {1, 0, 3, 2}, {1, 0, 3, 2}, {2, 3, 0, 1},
+    {2, 3, 0, 1}, {1, 0, 3, 2}, {1, 0, 3, 2}, {2, 3, 0, 1}, {0, 1, 2, 3}, {3, 2, 1, 0}, {3, 2, 1, 0}, {0, 1, 2, 3}};
+// G -> g5*G map, include/gamma.h:99-109: index[ig] = 15 - ig, sign = -1 for ig in {3,6,9,11,12,14}
+constexpr int kGammaMapSign[16] = {1, 1, 1, -1, 1, 1, -1, 1, 1, -1, 1, -1, -1, 1, -1, 1};
+
+// t += i^phase * z
+template <typename F> __device__ inline void add_phase(Cplx<F> &t, int phase, const Cplx<F> &z) {
+  switch (phase) {
+  case 0: t.re += z.re; t.im += z.im; break;
+  case 1: t.re -= z.im; t.im += z.re; break;
+  case 2: t.re -= z.re; t.im -= z.im; break;
+  default: t.re += z.im; t.im -= z.re; break;
+  }
+}
+
+// ---- QUDA even-odd index helpers (upstream QUDA index_helper.cuh) --------------
+struct Dims4 {
+  int x[4];
+};
+
+__host__ __device__ inline void get_coords(int c[4], int x_cb, const int X[4], int parity) {
+  const int za = x_cb / (X[0] >> 1);
+  const int zb = za / X[1];
+  c[1] = za - zb * X[1];
+  c[3] = zb / X[2];
+  c[2] = zb - c[3] * X[2];
+  const int x1odd = (c[1] + c[2] + c[3] + parity) & 1;
+  c[0] = 2 * x_cb + x1odd - za * X[0];
+}
+__host__ __device__ inline int lex_index(const int c[4], const int X[4]) {
+  return ((c[3] * X[2] + c[2]) * X[1] + c[1]) * X[0] + c[0];
+}
+// linkIndexShift(x, dx, X) with y[i] = (x[i] + dx[i] + X[i]) % X[i]
+__host__ __device__ inline int link_index_shift(const int c[4], const int dx[4], const int X[4]) {
+  int y[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) y[i] = (c[i] + dx[i] + X[i]) % X[i];
+  return lex_index(y, X) >> 1;
+}
+// ghostFaceIndex<bnd>(x, X, dim, nFace = 1) on the face: the leading term vanishes
+__host__ __device__ inline int ghost_face_index_on_face(const int c[4], const int X[4], int dim) {
+  int idx;
+  switch (dim) {
+  case 0: idx = (c[3] * X[2] + c[2]) * X[1] + c[1]; break;
+  case 1: idx = (c[3] * X[2] + c[2]) * X[0] + c[0]; break;
+  case 2: idx = (c[3] * X[1] + c[1]) * X[0] + c[0]; break;
+  default: idx = (c[2] * X[1] + c[1]) * X[0] + c[0]; break;
+  }
+  return idx >> 1;
+}
+
+// ---- native field accessors -------------------------------------------------------------------------
+// Spinor body (or ghost zone) in FLOAT2 / FLOAT4 order; see MugiqHipSpinorField in mugiq_hip.h.
+template <typename F, int ORDER> struct SpinorView {
+  F *base;
+  int stride;
+  int64_t parity_offset;  // complex elements
+
+  __device__ inline void load(Cplx<F> v[12], int parity, int x_cb) const {
+    const Cplx<F> *p = reinterpret_cast<const Cplx<F> *>(base) + parity * parity_offset;
+    if constexpr (ORDER == 2) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) v[k] = p[(int64_t)k * stride + x_cb];
+    } else {
+      struct alignas(4 * sizeof(F)) Pair {
+        Cplx<F> a, b;
+      };
+      const Pair *q = reinterpret_cast<const Pair *>(p);
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        Pair t = q[(int64_t)j * stride + x_cb];
+        v[2 * j] = t.a;
+        v[2 * j + 1] = t.b;
+      }
+    }
+  }
+  __device__ inline void store(const Cplx<F> v[12], int parity, int x_cb) const {
+    Cplx<F> *p = reinterpret_cast<Cplx<F> *>(base) + parity * parity_offset;
+    if constexpr (ORDER == 2) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) p[(int64_t)k * stride + x_cb] = v[k];
+    } else {
+      struct alignas(4 * sizeof(F)) Pair {
+        Cplx<F> a, b;
+      };
+      Pair *q = reinterpret_cast<Pair *>(p);
+#pragma unroll
+      for (int j = 0; j < 6; j++) q[(int64_t)j * stride + x_cb] = Pair{v[2 * j], v[2 * j + 1]};
+    }
+  }
+};
+
+template <typename F, int ORDER> inline SpinorView<F, ORDER> make_view(const MugiqHipSpinorField &f) {
+  return SpinorView<F, ORDER>{static_cast<F *>(f.data), f.stride, f.parity_offset};
+}
+template <typename F, int ORDER> inline SpinorView<F, ORDER> make_ghost_view(void *zone, int faceCB) {
+  return SpinorView<F, ORDER>{static_cast<F *>(zone), faceCB, (int64_t)12 * faceCB};
+}
+
+// Gauge field in native FLOAT2 order, 18 reals per link (reconstruct NO).
+template <typename F> struct GaugeView {
+  const F *base;
+  int stride;
+  int64_t parity_offset;
+  __device__ inline void load(Cplx<F> u[9], int dir, int parity, int x_cb) const {
+    const Cplx<F> *p = reinterpret_cast<const Cplx<F> *>(base) + parity * parity_offset + (int64_t)dir * 9 * stride + x_cb;
+#pragma unroll
+    for (int i = 0; i < 9; i++) u[i] = p[(int64_t)i * stride];
+  }
+};
+
+int validate_spinor(const MugiqHipSpinorField *f, const char *who, const char *name);
+bool same_geometry(const MugiqHipSpinorField &a, const MugiqHipSpinorField &b);
+
+}  // namespace mugiq

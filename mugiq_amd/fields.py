@@ -1,0 +1,159 @@
+"""Device fields in QUDA-native layouts, as plain torch buffers + the POD descriptors of the C ABI.
+
+These classes play the role of quda::ColorSpinorField / cudaGaugeField *as seen by the hot path*:
+a device pointer plus layout and geometry.  torch is used for device memory only.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+FLOAT2 = 2
+FLOAT4 = 4
+
+
+def _cdtype(precision):
+    return torch.complex128 if precision == 8 else torch.complex64
+
+
+def _np_cdtype(precision):
+    return np.complex128 if precision == 8 else np.complex64
+
+
+def spinor_native_index(order, parity, x_cb, s, c, stride, parity_offset):
+    """Complex-element index of component (s, c) at (parity, x_cb); see MugiqHipSpinorField in mugiq_hip.h."""
+    k = 3 * s + c
+    if order == FLOAT2:
+        return parity * parity_offset + k * stride + x_cb
+    return parity * parity_offset + ((k // 2) * stride + x_cb) * 2 + (k % 2)
+
+
+class SpinorField:
+    """nSpin=4, nColor=3 full-site-subset field in FLOAT2 or FLOAT4 order (plus optional depth-1 ghost zones)."""
+
+    def __init__(self, X, precision=8, order=FLOAT2, pad=0, device="cuda", data=None):
+        self.X = tuple(int(x) for x in X)
+        assert all(x > 0 and x % 2 == 0 for x in self.X), "local dims must be even"
+        self.precision = int(precision)
+        self.order = int(order)
+        self.volumeCB = int(np.prod(self.X)) // 2
+        self.stride = self.volumeCB + int(pad)
+        self.parity_offset = 12 * self.stride
+        self.device = torch.device(device)
+        n = 2 * self.parity_offset
+        if data is None:
+            self.data = torch.zeros(n, dtype=_cdtype(precision), device=self.device)
+        else:
+            assert data.numel() == n and data.dtype == _cdtype(precision)
+            self.data = data
+        self.ghost = [[None, None] for _ in range(4)]
+
+    def face_cb(self, dim):
+        return self.volumeCB // self.X[dim]
+
+    def alloc_ghost(self, dim, bnd):
+        if self.ghost[dim][bnd] is None:
+            self.ghost[dim][bnd] = torch.zeros(2 * 12 * self.face_cb(dim), dtype=self.data.dtype, device=self.device)
+        return self.ghost[dim][bnd]
+
+    def desc(self):
+        d = _lib.SpinorDesc()
+        d.data = self.data.data_ptr()
+        d.precision = self.precision
+        d.field_order = self.order
+        d.nParity = 2
+        d.volumeCB = self.volumeCB
+        d.stride = self.stride
+        for i in range(4):
+            d.X[i] = self.X[i]
+            for b in range(2):
+                g = self.ghost[i][b]
+                d.ghost[i][b] = g.data_ptr() if g is not None else None
+        d.parity_offset = self.parity_offset
+        return d
+
+    # ---- host <-> device plumbing in the logical shape [2, volumeCB, 4, 3] -------------------------------
+    def _index_table(self, vcb=None, stride=None, parity_offset=None):
+        vcb = self.volumeCB if vcb is None else vcb
+        stride = self.stride if stride is None else stride
+        parity_offset = self.parity_offset if parity_offset is None else parity_offset
+        p = np.arange(2).reshape(2, 1, 1, 1)
+        x = np.arange(vcb).reshape(1, vcb, 1, 1)
+        s = np.arange(4).reshape(1, 1, 4, 1)
+        c = np.arange(3).reshape(1, 1, 1, 3)
+        return spinor_native_index(self.order, p, x, s, c, stride, parity_offset)
+
+    def set_logical(self, v):
+        v = np.asarray(v)
+        assert v.shape == (2, self.volumeCB, 4, 3)
+        buf = np.zeros(2 * self.parity_offset, dtype=_np_cdtype(self.precision))
+        buf[self._index_table()] = v.astype(buf.dtype)
+        self.data.copy_(torch.from_numpy(buf))
+        return self
+
+    def get_logical(self):
+        buf = self.data.cpu().numpy()
+        return buf[self._index_table()]
+
+    def set_ghost_logical(self, dim, bnd, zone):
+        fcb = self.face_cb(dim)
+        zone = np.asarray(zone)
+        assert zone.shape == (2, fcb, 4, 3)
+        buf = np.zeros(2 * 12 * fcb, dtype=_np_cdtype(self.precision))
+        buf[self._index_table(fcb, fcb, 12 * fcb)] = zone.astype(buf.dtype)
+        self.alloc_ghost(dim, bnd).copy_(torch.from_numpy(buf))
+
+    def zone_to_logical(self, dim, zone_tensor):
+        fcb = self.face_cb(dim)
+        return zone_tensor.cpu().numpy()[self._index_table(fcb, fcb, 12 * fcb)]
+
+
+class GaugeField:
+    """Border-extended gauge field in native FLOAT2 order, 18 reals per link (what Displace builds at
+    lib/displace.cpp:104-134 of the reference)."""
+
+    def __init__(self, X, R=(0, 0, 0, 0), precision=8, pad=0, device="cuda"):
+        self.X = tuple(int(x) for x in X)
+        self.R = tuple(int(r) for r in R)
+        self.XE = tuple(self.X[d] + 2 * self.R[d] for d in range(4))
+        self.precision = int(precision)
+        self.volumeExCB = int(np.prod(self.XE)) // 2
+        self.stride = self.volumeExCB + int(pad)
+        self.parity_offset = 36 * self.stride
+        self.device = torch.device(device)
+        self.data = torch.zeros(2 * self.parity_offset, dtype=_cdtype(precision), device=self.device)
+
+    def desc(self):
+        d = _lib.GaugeDesc()
+        d.data = self.data.data_ptr()
+        d.precision = self.precision
+        for i in range(4):
+            d.X[i] = self.X[i]
+            d.R[i] = self.R[i]
+        d.stride = self.stride
+        d.parity_offset = self.parity_offset
+        return d
+
+    def set_logical(self, U):
+        """U: [4, 2, volExCB, 3, 3] (dir, parity, extended even-odd index, row, col)."""
+        U = np.asarray(U)
+        assert U.shape == (4, 2, self.volumeExCB, 3, 3)
+        d = np.arange(4).reshape(4, 1, 1, 1, 1)
+        p = np.arange(2).reshape(1, 2, 1, 1, 1)
+        x = np.arange(self.volumeExCB).reshape(1, 1, -1, 1, 1)
+        r = np.arange(3).reshape(1, 1, 1, 3, 1)
+        c = np.arange(3).reshape(1, 1, 1, 1, 3)
+        idx = p * self.parity_offset + (d * 9 + r * 3 + c) * self.stride + x
+        buf = np.zeros(2 * self.parity_offset, dtype=_np_cdtype(self.precision))
+        buf[idx] = U.astype(buf.dtype)
+        self.data.copy_(torch.from_numpy(buf))
+        return self
+
+
+def desc_array(fields):
+    arr = (_lib.SpinorDesc * len(fields))()
+    for i, f in enumerate(fields):
+        arr[i] = f.desc()
+    return arr

@@ -1,0 +1,119 @@
+"""Python mirror of MuGiq's operator API (lib/contract_wrappers.cu; declared at include/loop_mugiq.h:280-311
+and include/displace.h:109-111 of the reference) over the C ABI of libmugiq_hip.so.
+
+Same names and argument meaning as the reference's templated wrappers; <Float, order> come from the field
+descriptors instead of template parameters; errors raise MugiqHipError where the reference calls errorQuda.
+All functions enqueue on torch's current stream and return without synchronising.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .fields import SpinorField, GaugeField, desc_array
+
+N_GAMMA = 16
+DispDir = {"x": 0, "y": 1, "z": 2, "t": 3}          # include/enum_mugiq.h:72-78
+DispSignMinus, DispSignPlus = 0, 1                   # include/enum_mugiq.h:81-85
+LOOP_FT_SIGN_MINUS, LOOP_FT_SIGN_PLUS = -1, 1        # include/enum_mugiq.h:28-33
+DisplaceFlagArray = ["+x", "-x", "+y", "-y", "+z", "-z", "+t", "-t"]   # include/displace.h:21
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _prec_of(t):
+    if t.dtype == torch.complex128:
+        return 8
+    if t.dtype == torch.complex64:
+        return 4
+    raise TypeError("loop buffers must be complex64 or complex128 tensors")
+
+
+def copyGammaCoeffStructToSymbol(precision):
+    _lib.check(_lib.load().mugiq_hip_copy_gamma_coeff_to_symbol(int(precision)))
+
+
+def copyGammaMapStructToSymbol(precision):
+    _lib.check(_lib.load().mugiq_hip_copy_gamma_map_to_symbol(int(precision)))
+
+
+def gammaTables():
+    """(row_value[16][4] complex, column_index[16][4], map_sign[16], map_index[16]) the kernels were built with."""
+    rv = (ctypes.c_double * 128)()
+    ci = (ctypes.c_int * 64)()
+    ms = (ctypes.c_double * 16)()
+    mi = (ctypes.c_int * 16)()
+    _lib.check(_lib.load().mugiq_hip_get_gamma_tables(rv, ci, ms, mi))
+    rv = np.array(rv).reshape(16, 4, 2)
+    return rv[..., 0] + 1j * rv[..., 1], np.array(ci).reshape(16, 4), np.array(ms), np.array(mi)
+
+
+def GammaName(m):
+    s = _lib.load().mugiq_hip_gamma_name(int(m))
+    if s is None:
+        raise IndexError(m)
+    return s.decode()
+
+
+def performLoopContraction(loopData_d, eVecL, eVecR, sigma):
+    """loopData[tid + V*iG] += (1/sigma) vL^dag(x) G(iG) vR(x)      lib/contract_wrappers.cu:88-115"""
+    assert isinstance(eVecL, SpinorField) and isinstance(eVecR, SpinorField)
+    assert _prec_of(loopData_d) == eVecL.precision and loopData_d.numel() >= N_GAMMA * 2 * eVecL.volumeCB
+    dl, dr = eVecL.desc(), eVecR.desc()
+    _lib.check(_lib.load().mugiq_hip_perform_loop_contraction(loopData_d.data_ptr(), ctypes.byref(dl), ctypes.byref(dr),
+                                                               float(sigma), _stream()))
+
+
+def performLoopContractionBatched(loopData_d, eVecsL, eVecsR, sigmas):
+    """The eigenvector loop of Loop_Mugiq::computeCoarseLoop (lib/loop_mugiq.cpp:478-503) in one launch."""
+    n = len(eVecsL)
+    assert len(eVecsR) == n and len(sigmas) == n and n >= 1
+    assert _prec_of(loopData_d) == eVecsL[0].precision and loopData_d.numel() >= N_GAMMA * 2 * eVecsL[0].volumeCB
+    L = desc_array(eVecsL)
+    R = L if eVecsR is eVecsL else desc_array(eVecsR)
+    sg = (ctypes.c_double * n)(*[float(s) for s in sigmas])
+    _lib.check(_lib.load().mugiq_hip_perform_loop_contraction_batched(loopData_d.data_ptr(), L, R, sg, n, _stream()))
+
+
+def performCovariantDisplacementVector(dst, src, gauge, dispDir, dispSign, commDim=(0, 0, 0, 0)):
+    """dst(x) = U_d(x) src(x+d) | U_d^dag(x-d) src(x-d)            lib/contract_wrappers.cu:171-198.
+    The halo exchange (exchangeGhostVec) must have filled src.ghost for partitioned dims."""
+    assert isinstance(gauge, GaugeField)
+    dd, ds, dg = dst.desc(), src.desc(), gauge.desc()
+    _lib.check(_lib.load().mugiq_hip_perform_covariant_displacement_vector(
+        ctypes.byref(dd), ctypes.byref(ds), ctypes.byref(dg), int(dispDir), int(dispSign), _lib.int4(commDim), _stream()))
+
+
+def packFace(face_d, src, dim, high):
+    """Send half of exchangeGhostVec: face of `src` in ghost-zone layout (see mugiq_hip_pack_face)."""
+    ds = src.desc()
+    assert face_d.numel() >= 2 * 12 * src.face_cb(dim) and face_d.dtype == src.data.dtype
+    _lib.check(_lib.load().mugiq_hip_pack_face(face_d.data_ptr(), ctypes.byref(ds), int(dim), int(high), _stream()))
+
+
+def createPhaseMatrixGPU(phaseMatrix_d, momMatrix_h, locV3, Nmom, FTSign, localL, totalL, commCoord=(0, 0, 0, 0)):
+    """ph[v3 + locV3*im] = exp(i FTSign 2pi p.x/L)                 lib/contract_wrappers.cu:50-77"""
+    mom = np.ascontiguousarray(np.asarray(momMatrix_h, dtype=np.int32).reshape(-1))
+    assert mom.size == 3 * Nmom and phaseMatrix_d.numel() >= locV3 * Nmom
+    _lib.check(_lib.load().mugiq_hip_create_phase_matrix(
+        phaseMatrix_d.data_ptr(), mom.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), int(locV3), int(Nmom), int(FTSign),
+        _lib.int4(localL), _lib.int4(totalL), _lib.int4(commCoord), _prec_of(phaseMatrix_d), _stream()))
+
+
+def convertIdxOrder_mapGamma(dataPosMP_d, dataPos_d, nData, nLoop, nParity, volumeCB, localL):
+    """even-odd [nData][V] -> [v3][nData][t] with the G -> g5 G map  lib/contract_wrappers.cu:133-156"""
+    assert dataPosMP_d.dtype == dataPos_d.dtype and dataPosMP_d.numel() >= nData * nParity * volumeCB
+    _lib.check(_lib.load().mugiq_hip_convert_idx_order_map_gamma(
+        dataPosMP_d.data_ptr(), dataPos_d.data_ptr(), int(nData), int(nLoop), int(nParity), int(volumeCB),
+        _lib.int4(localL), _prec_of(dataPos_d), _stream()))
+
+
+def momentumProjection(dataMom_d, dataPosMP_d, phaseMatrix_d, locT, nData, locV3, Nmom):
+    """dataMom[M x N] = dataPosMP[M x K] phase[K x N] (the Zgemm/Cgemm of lib/loop_mugiq.cpp:363-378)"""
+    assert dataMom_d.numel() >= locT * nData * Nmom
+    _lib.check(_lib.load().mugiq_hip_momentum_projection(
+        dataMom_d.data_ptr(), dataPosMP_d.data_ptr(), phaseMatrix_d.data_ptr(), int(locT), int(nData), int(locV3),
+        int(Nmom), _prec_of(dataPosMP_d), None, 0, _stream()))

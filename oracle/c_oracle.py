@@ -1,0 +1,48 @@
+"""ctypes wrapper of oracle/libmugiq_oracle.so (the plain-C restatement of the contraction).
+TEST INFRASTRUCTURE ONLY -- see the header of oracle/mugiq_oracle.c."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "libmugiq_oracle.so")
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            raise ImportError("%s missing: run `make -C oracle`" % _PATH)
+        _lib = ctypes.CDLL(_PATH)
+        _lib.oracle_num_threads.restype = ctypes.c_int
+        for name in ("oracle_loop_contract_f64", "oracle_loop_contract_f32"):
+            f = getattr(_lib, name)
+            f.restype = None
+            f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                          ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                          ctypes.c_int64, ctypes.c_int64, ctypes.c_int]
+    return _lib
+
+
+def num_threads():
+    return load().oracle_num_threads()
+
+
+def loop_contract_native(loop, vL_bufs, vR_bufs, sigmas, volumeCB, stride, parity_offset, order,
+                         site_begin=0, site_end=None):
+    """loop (flat complex numpy, 16*V) += sum_n (1/sigma_n) vL_n^dag G vR_n over sites [site_begin, site_end);
+    vL_bufs / vR_bufs: lists of flat native-layout complex numpy buffers (FLOAT2 / FLOAT4 order)."""
+    lib = load()
+    n = len(vL_bufs)
+    f64 = loop.dtype == np.complex128
+    for b in list(vL_bufs) + list(vR_bufs):
+        assert b.dtype == loop.dtype and b.flags["C_CONTIGUOUS"]
+    pl = (ctypes.c_void_p * n)(*[b.ctypes.data for b in vL_bufs])
+    pr = (ctypes.c_void_p * n)(*[b.ctypes.data for b in vR_bufs])
+    sg = (ctypes.c_double * n)(*[float(s) for s in sigmas])
+    site_end = 2 * volumeCB if site_end is None else site_end
+    fn = lib.oracle_loop_contract_f64 if f64 else lib.oracle_loop_contract_f32
+    fn(loop.ctypes.data, pl, pr, sg, n, site_begin, site_end, volumeCB, stride, parity_offset, order)
+    return loop

@@ -1,0 +1,302 @@
+"""GPU parity tests: every operator of the C ABI against the CPU oracle on the same seeded inputs.
+
+Tolerances (north_star): complex loop traces 1e-12 (fp64) / 1e-5 (fp32), relative to the largest element;
+displacement INDEXING bit-exact (checked with integer-valued fields and unit links, where every output is
+an exact copy of one input element).
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import orc, random_gauge_lex, random_spinor_lex, unit_gauge_lex, sigmas, momenta_p2_le, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {8: 1e-12, 4: 1e-5}
+CASES = [(8, 2), (8, 4), (4, 2), (4, 4)]          # (precision, field order): the reference's four instantiations
+
+
+def _np_c(prec):
+    return np.complex128 if prec == 8 else np.complex64
+
+
+def _field(hip, v, X, prec, order, pad=0):
+    return hip.SpinorField(X, prec, order, pad=pad).set_logical(v.astype(_np_c(prec)))
+
+
+def _rounded(v, prec):
+    """The inputs the GPU actually sees (fp32 cases are checked against the fp64 oracle on rounded inputs)."""
+    return v.astype(_np_c(prec)).astype(np.complex128)
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec,order", CASES)
+@pytest.mark.parametrize("X", [(4, 4, 4, 4), (8, 4, 6, 2), (8, 8, 8, 8)])
+def test_loop_contraction_single_and_batched(hip, prec, order, X):
+    rng = np.random.default_rng(101)
+    nev = 5
+    V = int(np.prod(X))
+    evL = [orc.lex_to_eo(random_spinor_lex(rng, X), X) for _ in range(nev)]
+    evR = [orc.lex_to_eo(random_spinor_lex(rng, X), X) for _ in range(nev)]
+    sg = sigmas(nev)
+    fL = [_field(hip, v, X, prec, order) for v in evL]
+    fR = [_field(hip, v, X, prec, order) for v in evR]
+    cdt = torch.complex128 if prec == 8 else torch.complex64
+
+    # oracle in fp64 on the rounded inputs
+    ref_lr = np.zeros(16 * V, dtype=np.complex128)
+    ref_ll = np.zeros(16 * V, dtype=np.complex128)
+    for n in range(nev):
+        orc.loop_contract(ref_lr, _rounded(evL[n], prec), _rounded(evR[n], prec), sg[n])
+        orc.loop_contract(ref_ll, _rounded(evL[n], prec), _rounded(evL[n], prec), sg[n])
+
+    # one call per eigenvector, accumulating in place like the reference (lib/loop_mugiq.cpp:493,502)
+    loop = torch.zeros(16 * V, dtype=cdt, device="cuda")
+    for n in range(nev):
+        hip.performLoopContraction(loop, fL[n], fR[n], sg[n])
+    assert rel_err(loop.cpu().numpy(), ref_lr) < TOL[prec]
+
+    # batched, L != R
+    loop_b = torch.zeros(16 * V, dtype=cdt, device="cuda")
+    hip.performLoopContractionBatched(loop_b, fL, fR, sg)
+    assert rel_err(loop_b.cpu().numpy(), ref_lr) < TOL[prec]
+
+    # batched ultra-local (L == R, Hermitian kernel) with odd and even batch sizes, accumulating on top
+    loop_u = torch.zeros(16 * V, dtype=cdt, device="cuda")
+    hip.performLoopContractionBatched(loop_u, fL[:3], fL[:3], sg[:3])
+    hip.performLoopContractionBatched(loop_u, fL[3:], fL[3:], sg[3:])
+    assert rel_err(loop_u.cpu().numpy(), ref_ll) < TOL[prec]
+    # single-vector ultra-local path agrees too
+    loop_s = torch.zeros(16 * V, dtype=cdt, device="cuda")
+    for n in range(nev):
+        hip.performLoopContraction(loop_s, fL[n], fL[n], sg[n])
+    assert rel_err(loop_s.cpu().numpy(), ref_ll) < TOL[prec]
+
+
+def test_loop_contraction_padded_stride_and_ragged_volume(hip):
+    """pad != 0 (stride > volumeCB) and a volume that is not a multiple of the workgroup size."""
+    X = (6, 4, 2, 2)          # V = 96 sites: one partially filled workgroup
+    rng = np.random.default_rng(7)
+    v = orc.lex_to_eo(random_spinor_lex(rng, X), X)
+    w = orc.lex_to_eo(random_spinor_lex(rng, X), X)
+    V = int(np.prod(X))
+    ref = np.zeros(16 * V, dtype=np.complex128)
+    orc.loop_contract(ref, v, w, 0.37)
+    for order in (2, 4):
+        a = hip.SpinorField(X, 8, order, pad=10).set_logical(v)
+        b = hip.SpinorField(X, 8, order, pad=10).set_logical(w)
+        loop = torch.zeros(16 * V, dtype=torch.complex128, device="cuda")
+        hip.performLoopContraction(loop, a, b, 0.37)
+        assert rel_err(loop.cpu().numpy(), ref) < 1e-13
+
+
+def test_gamma_unit_slot_property_full_precision(hip):
+    """Size-independent property: sum_x loop[x, G=1] = sum_n ||v_n||^2 / sigma_n; G=1 slot is real."""
+    X = (8, 8, 8, 16)
+    rng = np.random.default_rng(3)
+    nev = 6
+    V = int(np.prod(X))
+    f = []
+    for _ in range(nev):
+        v = torch.randn(2 * 12 * (V // 2), dtype=torch.complex128, device="cuda")
+        v /= torch.linalg.vector_norm(v)
+        f.append(hip.SpinorField(X, 8, 2, data=v))
+    sg = sigmas(nev)
+    loop = torch.zeros(16 * V, dtype=torch.complex128, device="cuda")
+    hip.performLoopContractionBatched(loop, f, f, sg)
+    one = loop[:V]
+    assert abs(one.sum().item() - np.sum(1.0 / sg)) < 1e-11 * np.sum(1.0 / sg)
+    assert torch.max(torch.abs(one.imag)).item() == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec,order", CASES)
+@pytest.mark.parametrize("X", [(4, 4, 4, 4), (4, 6, 8, 2)])
+def test_displacement_indexing_is_bit_exact(hip, prec, order, X):
+    """Unit links + integer-valued spinor: every output element must be an exact copy of the right input."""
+    V = int(np.prod(X))
+    lexid = np.arange(V).reshape(X[3], X[2], X[1], X[0])
+    psi_lex = (lexid[..., None, None] * 12 + np.arange(12).reshape(4, 3)).astype(np.float64)
+    psi_lex = psi_lex + 1j * (psi_lex + 0.5)              # all exactly representable in fp32 (< 2^24) and fp64
+    psi = orc.lex_to_eo(psi_lex, X)
+    U = hip.GaugeField(X, (0, 0, 0, 0), prec).set_logical(
+        orc.extended_gauge_from_global(unit_gauge_lex(X), (0, 0, 0, 0), (1, 1, 1, 1), (0, 0, 0, 0)))
+    src = _field(hip, psi, X, prec, order)
+    dst = hip.SpinorField(X, prec, order)
+    Uo = orc.extended_gauge_from_global(unit_gauge_lex(X), (0, 0, 0, 0), (1, 1, 1, 1), (0, 0, 0, 0))
+    for dirn in range(4):
+        for sign in (hip.DispSignPlus, hip.DispSignMinus):
+            hip.performCovariantDisplacementVector(dst, src, U, dirn, sign)
+            exp = orc.covariant_displacement(psi, Uo, dirn, sign, X)
+            assert np.array_equal(dst.get_logical().astype(np.complex128), exp)
+
+
+@pytest.mark.parametrize("prec,order", CASES)
+def test_displacement_random_su3_and_inverse_property(hip, prec, order):
+    X = (4, 4, 6, 8)
+    rng = np.random.default_rng(17)
+    psi = orc.lex_to_eo(random_spinor_lex(rng, X), X)
+    U_lex = random_gauge_lex(rng, X)
+    Uo = orc.extended_gauge_from_global(U_lex, (0, 0, 0, 0), (1, 1, 1, 1), (0, 0, 0, 0))
+    U = hip.GaugeField(X, (0, 0, 0, 0), prec).set_logical(Uo)
+    src = _field(hip, psi, X, prec, order)
+    a = hip.SpinorField(X, prec, order)
+    b = hip.SpinorField(X, prec, order)
+    Ur = Uo.astype(_np_c(prec)).astype(np.complex128)
+    for dirn in range(4):
+        for sign in (hip.DispSignPlus, hip.DispSignMinus):
+            hip.performCovariantDisplacementVector(a, src, U, dirn, sign)
+            exp = orc.covariant_displacement(_rounded(psi, prec), Ur, dirn, sign, X)
+            assert rel_err(a.get_logical(), exp) < (1e-14 if prec == 8 else 1e-6)
+            hip.performCovariantDisplacementVector(b, a, U, dirn, 1 - sign)        # D_-mu D_+mu = 1
+            assert rel_err(b.get_logical(), psi) < (1e-12 if prec == 8 else 1e-5)
+
+
+@pytest.mark.parametrize("order", [2, 4])
+def test_displacement_with_ghost_zones_matches_single_domain(hip, order):
+    """Two domains along t and z emulated on one GPU: pack faces with the HIP packer, hand them over as ghost
+    zones, displace with the border-2 extended gauge, compare with the single-domain oracle."""
+    G = (4, 4, 8, 8)
+    rng = np.random.default_rng(23)
+    psi_lex = random_spinor_lex(rng, G)
+    U_lex = random_gauge_lex(rng, G)
+    single_U = orc.extended_gauge_from_global(U_lex, (0, 0, 0, 0), (1, 1, 1, 1), (0, 0, 0, 0))
+    psi_g = orc.lex_to_eo(psi_lex, G)
+    for grid in [(1, 1, 1, 2), (1, 1, 2, 1), (2, 1, 1, 1), (1, 2, 1, 1)]:
+        comm = [1 if g > 1 else 0 for g in grid]
+        brd = [2 * c for c in comm]
+        pdim = comm.index(1)
+        l = [G[d] // grid[d] for d in range(4)]
+        ranks = [tuple(1 if (d == pdim and r == 1) else 0 for d in range(4)) for r in range(2)]
+        f = {r: _field(hip, orc.lex_to_eo(orc.local_block(psi_lex, r, grid), l), l, 8, order) for r in ranks}
+        Ue = {r: hip.GaugeField(l, brd, 8).set_logical(orc.extended_gauge_from_global(U_lex, r, grid, brd)) for r in ranks}
+        # faces: HIP packer == oracle packer, then install as the neighbour's ghost zones
+        for r in ranks:
+            other = ranks[1 - ranks.index(r)]
+            for high in (0, 1):
+                face = torch.zeros(2 * 12 * f[r].face_cb(pdim), dtype=torch.complex128, device="cuda")
+                hip.packFace(face, f[r], pdim, high)
+                got = f[r].zone_to_logical(pdim, face)
+                assert np.array_equal(got, orc.pack_face(f[r].get_logical(), l, pdim, high))
+                # low face -> backward neighbour's forward zone (bnd 1); high face -> forward neighbour's bnd 0
+                f[other].alloc_ghost(pdim, 1 - high).copy_(face)
+        for dirn in range(4):
+            for sign in (hip.DispSignPlus, hip.DispSignMinus):
+                exp_g = orc.eo_to_lex(orc.covariant_displacement(psi_g, single_U, dirn, sign, G), G)
+                for r in ranks:
+                    dst = hip.SpinorField(l, 8, order)
+                    hip.performCovariantDisplacementVector(dst, f[r], Ue[r], dirn, sign, comm)
+                    got = orc.eo_to_lex(dst.get_logical(), l)
+                    assert rel_err(got, orc.local_block(exp_g, r, grid)) < 1e-14, (grid, dirn, sign, r)
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", [8, 4])
+@pytest.mark.parametrize("FTSign", [1, -1])
+def test_phase_matrix(hip, prec, FTSign):
+    localL, totalL, cc = (4, 6, 8, 4), (8, 6, 16, 8), (1, 0, 1, 1)
+    moms = momenta_p2_le(3)
+    locV3 = localL[0] * localL[1] * localL[2]
+    ph = torch.zeros(locV3 * len(moms), dtype=torch.complex128 if prec == 8 else torch.complex64, device="cuda")
+    hip.createPhaseMatrixGPU(ph, moms, locV3, len(moms), FTSign, localL, totalL, cc)
+    exp = orc.phase_matrix(moms, locV3, FTSign, localL, totalL, cc, np.float64 if prec == 8 else np.float32)
+    assert rel_err(ph.cpu().numpy(), exp) < (1e-15 if prec == 8 else 2e-7)
+
+
+@pytest.mark.parametrize("prec", [8, 4])
+@pytest.mark.parametrize("X,nLoop", [((4, 4, 4, 4), 1), ((6, 4, 2, 8), 3), ((8, 8, 8, 4), 2)])
+def test_convert_idx_order_map_gamma_is_exact(hip, prec, X, nLoop):
+    rng = np.random.default_rng(5)
+    V = int(np.prod(X))
+    nData = 16 * nLoop
+    cdt = np.complex128 if prec == 8 else np.complex64
+    data = (rng.standard_normal(nData * V) + 1j * rng.standard_normal(nData * V)).astype(cdt)
+    d_in = torch.from_numpy(data).cuda()
+    d_out = torch.zeros_like(d_in)
+    hip.convertIdxOrder_mapGamma(d_out, d_in, nData, nLoop, 2, V // 2, X)
+    exp = orc.convert_idx_order_map_gamma(data, nData, nLoop, 2, V // 2, X)
+    assert np.array_equal(d_out.cpu().numpy(), exp)          # permutation + sign flip: bit-exact
+
+
+@pytest.mark.parametrize("prec", [8, 4])
+@pytest.mark.parametrize("locT,nData,L3,Nmom", [(4, 16, (4, 4, 4), 7), (8, 32, (8, 6, 4), 19), (2, 16, (6, 2, 2), 1),
+                                                (16, 48, (8, 8, 8), 33)])
+def test_momentum_projection_vs_oracle_gemm(hip, prec, locT, nData, L3, Nmom):
+    rng = np.random.default_rng(9)
+    locV3 = L3[0] * L3[1] * L3[2]
+    M = locT * nData
+    cdt = np.complex128 if prec == 8 else np.complex64
+    A = (rng.standard_normal(M * locV3) + 1j * rng.standard_normal(M * locV3)).astype(cdt)
+    B = (rng.standard_normal(locV3 * Nmom) + 1j * rng.standard_normal(locV3 * Nmom)).astype(cdt)
+    out = torch.zeros(M * Nmom, dtype=torch.complex128 if prec == 8 else torch.complex64, device="cuda")
+    hip.momentumProjection(out, torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), locT, nData, locV3, Nmom)
+    exp = orc.momentum_projection_local(A.astype(np.complex128), B.astype(np.complex128), locT, nData, locV3, Nmom)
+    assert rel_err(out.cpu().numpy(), exp) < (1e-13 if prec == 8 else 1e-5)
+
+
+def test_full_pipeline_ultralocal_and_displaced_vs_oracle(hip):
+    """cfg1-like plumbing on the GPU: 8^4... scaled to 4^3x8, N_ev=4, ultra-local + displaced loops,
+    reorder, phases, momentum projection -- operator by operator in the reference's order."""
+    X = (4, 4, 4, 8)
+    rng = np.random.default_rng(77)
+    nev = 4
+    V = int(np.prod(X))
+    ev = [orc.lex_to_eo(random_spinor_lex(rng, X), X) for _ in range(nev)]
+    U_lex = random_gauge_lex(rng, X)
+    Uo = orc.extended_gauge_from_global(U_lex, (0, 0, 0, 0), (1, 1, 1, 1), (0, 0, 0, 0))
+    sg = sigmas(nev)
+    cprm = orc.LoopComputeParam(["+z", "-x", "+t"], [1, 2, 1], [2, 2, 3])
+    ref_pos = orc.compute_loop_position_space(ev, sg, cprm, Uo, X)
+
+    f = [_field(hip, v, X, 8, 2) for v in ev]
+    U = hip.GaugeField(X, (0, 0, 0, 0), 8).set_logical(Uo)
+    perLoop = 16 * V
+    dataPos = torch.zeros(perLoop * cprm.nLoop, dtype=torch.complex128, device="cuda")
+    a, b = hip.SpinorField(X, 8, 2), hip.SpinorField(X, 8, 2)
+    for idx in range(-1, cprm.nDispEntries):
+        for n in range(nev):
+            if idx < 0:
+                hip.performLoopContraction(dataPos[:perLoop], f[n], f[n], sg[n])
+                continue
+            dirn, sign = orc.parse_displacement(cprm.dispString[idx])
+            cur, nxt = f[n], a
+            cnt = 0
+            for idisp in range(1, cprm.dispStop[idx] + 1):
+                hip.performCovariantDisplacementVector(nxt, cur, U, dirn, sign)
+                cur, nxt = nxt, (b if nxt is a else a)
+                if cprm.dispStart[idx] <= idisp:
+                    s0 = perLoop * (cprm.nLoopOffset[idx] + cnt)
+                    hip.performLoopContraction(dataPos[s0:s0 + perLoop], f[n], cur, sg[n])
+                    cnt += 1
+    assert rel_err(dataPos.cpu().numpy(), ref_pos) < 1e-12
+
+    moms = momenta_p2_le(2)
+    locV3 = X[0] * X[1] * X[2]
+    ph = torch.zeros(locV3 * len(moms), dtype=torch.complex128, device="cuda")
+    hip.createPhaseMatrixGPU(ph, moms, locV3, len(moms), -1, X, X)
+    mp = torch.zeros_like(dataPos)
+    hip.convertIdxOrder_mapGamma(mp, dataPos, cprm.nData, cprm.nLoop, 2, V // 2, X)
+    mom = torch.zeros(X[3] * cprm.nData * len(moms), dtype=torch.complex128, device="cuda")
+    hip.momentumProjection(mom, mp, ph, X[3], cprm.nData, locV3, len(moms))
+    ref_mp = orc.convert_idx_order_map_gamma(ref_pos, cprm.nData, cprm.nLoop, 2, V // 2, X)
+    ref_mom = orc.momentum_projection_local(ref_mp, orc.phase_matrix(moms, locV3, -1, X, X), X[3], cprm.nData, locV3, len(moms))
+    assert rel_err(mom.cpu().numpy(), ref_mom) < 1e-12
+
+
+def test_errors_are_loud(hip):
+    X = (4, 4, 4, 4)
+    a, b = hip.SpinorField(X, 8, 2), hip.SpinorField(X, 4, 4)
+    loop = torch.zeros(16 * 256, dtype=torch.complex128, device="cuda")
+    with pytest.raises(hip.MugiqHipError):
+        hip.performLoopContractionBatched(loop, [a], [b], [1.0])          # mismatched precision/order
+    with pytest.raises(hip.MugiqHipError):
+        hip.performLoopContraction(loop, a, a, 0.0)                         # sigma = 0
+    U = hip.GaugeField(X, (0, 0, 0, 0), 8)
+    with pytest.raises(hip.MugiqHipError):
+        hip.performCovariantDisplacementVector(a, a, U, 0, 1)               # aliasing
+    c = hip.SpinorField(X, 8, 2)
+    with pytest.raises(hip.MugiqHipError):
+        hip.performCovariantDisplacementVector(c, a, U, 3, 1, (0, 0, 0, 1))  # partitioned but no ghost zone
+    with pytest.raises(hip.MugiqHipError):
+        big = torch.zeros(17 * 256, dtype=torch.complex128, device="cuda")
+        hip.convertIdxOrder_mapGamma(torch.zeros_like(big), big, 17, 1, 2, 128, X)     # nData != 16*nLoop

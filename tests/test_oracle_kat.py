@@ -297,3 +297,28 @@ def test_parse_displacement_strings_and_bookkeeping():
     assert c.dispStart == [1, 3, 2] and c.dispStop == [8, 3, 5]       # start > stop are swapped
     assert c.nLoopPerEntry == [8, 1, 4] and c.nLoopOffset == [1, 9, 10] and c.nLoop == 14 and c.nData == 224
     assert orc.LoopComputeParam(doNonLocal=False).nLoop == 1
+
+
+# ---- the plain-C restatement (cpu_baseline "port") agrees with the numpy oracle ------------------------
+@pytest.mark.parametrize("order", [orc.FLOAT2, orc.FLOAT4])
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+def test_c_oracle_matches_numpy_oracle(order, dtype):
+    from oracle import c_oracle
+    X = (4, 4, 6, 2)
+    rng = np.random.default_rng(41)
+    nev = 3
+    V = int(np.prod(X))
+    evL = [orc.lex_to_eo(random_spinor_lex(rng, X), X).astype(dtype) for _ in range(nev)]
+    evR = [orc.lex_to_eo(random_spinor_lex(rng, X), X).astype(dtype) for _ in range(nev)]
+    sg = sigmas(nev)
+    fdt = np.float64 if dtype == np.complex128 else np.float32
+    ref = np.zeros(16 * V, dtype=dtype)
+    for n in range(nev):
+        orc.loop_contract(ref, evL[n], evR[n], sg[n], fdt)
+    stride = V // 2 + 6
+    bl = [orc.spinor_to_native(v, order, stride=stride) for v in evL]
+    br = [orc.spinor_to_native(v, order, stride=stride) for v in evR]
+    got = np.zeros(16 * V, dtype=dtype)
+    c_oracle.loop_contract_native(got, bl, br, sg, V // 2, stride, 12 * stride, order)
+    assert rel_err(got, ref) < (1e-15 if dtype == np.complex128 else 1e-6)
+    assert c_oracle.num_threads() >= 1
