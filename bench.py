@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native MuGiq loop engine.
+
+Metric (BASELINE.json): loop-trace sites/s, one "site" = all 16 gamma traces summed over all N_ev low modes
+at one lattice site, plus achieved HBM GB/s against the 8 TB/s roofline.
+
+Workload at N=1 (BASELINE.json configs[1]): 32^4 Wilson-clover fp64, N_ev=200, ultra-local 16-gamma loop.
+A "step" is one pass of the hot path over the whole local lattice: zero the loop slot
+(lib/loop_mugiq.cpp:476) + the eigenvector-batched contraction (lib/loop_mugiq.cpp:478-503 folded into one
+launch of loop_contract_kernel).  Inputs are synthetic (seeded Gaussian unit-norm eigenvectors, sigma_n =
+0.01 + 0.002 n) and resident in HBM before the timed region.
+
+N>1: the lattice is block-partitioned over ranks (T first, then Z); the ultra-local contraction has no
+inter-site coupling, so ranks run independently on their local 32^4 block (weak scaling, no data-path
+collective); value = total sites / max-over-ranks time.
+
+Usage: python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--lattice", type=int, nargs=4, default=[32, 32, 32, 32], help="LOCAL lattice per GPU (x y z t)")
+    ap.add_argument("--nev", type=int, default=200)
+    ap.add_argument("--precision", type=int, default=8, choices=[4, 8])
+    ap.add_argument("--order", type=int, default=2, choices=[2, 4])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def make_evecs(hip, X, nev, prec, order, device, seed):
+    """N_ev synthetic eigenvectors in one HBM allocation (native layout), each globally unit-norm."""
+    vcb = int(np.prod(X)) // 2
+    per = 2 * 12 * vcb
+    cdt = torch.complex128 if prec == 8 else torch.complex64
+    big = torch.empty(nev * per, dtype=cdt, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    fields = []
+    for n in range(nev):
+        v = big[n * per:(n + 1) * per]
+        re = torch.randn(per, dtype=torch.float64, device=device, generator=g)
+        im = torch.randn(per, dtype=torch.float64, device=device, generator=g)
+        w = torch.complex(re, im)
+        w /= torch.linalg.vector_norm(w)
+        v.copy_(w.to(cdt))
+        fields.append(hip.SpinorField(X, prec, order, data=v))
+        del re, im, w
+    return big, fields
+
+
+def cpu_baseline(fields, sigmas, X, prec, order, budget_s):
+    """Time the plain-C restatement of the reference kernel (oracle/mugiq_oracle.c, `port`) on the host cores,
+    on a bounded sample of the same workload: the first S even + S odd checkerboard sites of every eigenvector."""
+    from oracle import c_oracle
+    nev = len(fields)
+    vcb = fields[0].volumeCB
+    S = min(vcb, 32768)                     # sample: 2*S sites x all N_ev eigenvectors
+    cdt = np.complex128 if prec == 8 else np.complex64
+    bufs = []
+    for f in fields:
+        d = f.data.view(2, -1)              # [parity][12*stride] complex (parity_offset = 12*stride)
+        if order == 2:
+            h = d.view(2, 12, f.stride)[:, :, :S].contiguous().cpu().numpy()              # planes of S sites
+        else:
+            h = d.view(2, 6, f.stride, 2)[:, :, :S, :].contiguous().cpu().numpy()
+        bufs.append(np.ascontiguousarray(h.reshape(-1)).astype(cdt, copy=False))
+    loop = np.zeros(16 * 2 * S, dtype=cdt)
+    threads = c_oracle.num_threads()
+    c_oracle.loop_contract_native(loop, bufs, bufs, sigmas, S, S, 12 * S, order)        # warm-up pass
+    t0 = time.perf_counter()
+    passes = 0
+    while True:
+        loop[:] = 0
+        c_oracle.loop_contract_native(loop, bufs, bufs, sigmas, S, S, 12 * S, order)
+        passes += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or passes >= 1000:
+            break
+    sites_per_s = passes * 2 * S / el
+    return {"value": sites_per_s, "unit": "sites/s", "cores": threads, "kind": "port",
+            "sample": "%d sites x %d eigenvectors (first %d checkerboard sites of each parity of the bench fields), "
+                      "%d passes in %.1f s, oracle/mugiq_oracle.c with OpenMP" % (2 * S, nev, S, passes, el)}, loop, S
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    import mugiq_amd as hip            # raises if libmugiq_hip.so is missing: there is no fallback
+
+    X = tuple(a.lattice)
+    V = int(np.prod(X))
+    prec, order, nev = a.precision, a.order, a.nev
+    B = prec
+    sig = 0.01 + 0.002 * np.arange(nev)
+    big, fields = make_evecs(hip, X, nev, prec, order, device, seed=777 + rank)
+    cdt = torch.complex128 if prec == 8 else torch.complex64
+    loop = torch.zeros(16 * V, dtype=cdt, device=device)
+
+    def step():
+        loop.zero_()                                                     # cudaMemset, lib/loop_mugiq.cpp:476
+        hip.performLoopContractionBatched(loop, fields, fields, sig)     # lib/loop_mugiq.cpp:478-503
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    # ---- timed region: exactly K steps ---------------------------------------------------------------
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loop.zero_()
+        ev0[i].record()                                                  # same (current) stream as the kernel
+        hip.performLoopContractionBatched(loop, fields, fields, sig)
+        ev1[i].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # ---------------------------------------------------------------------------------------------------
+    kern_ms = float(np.mean([ev0[i].elapsed_time(ev1[i]) for i in range(a.steps)]))
+    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kern_ms = float(t[0]), float(t[1])
+    ms_per_step = elapsed * 1e3 / a.steps
+    value = world * V / (ms_per_step * 1e-3)
+
+    alg_bytes = V * (nev * 24 * B + 32 * B)          # per site N_ev*24*B read + 32*B written
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    workload = "%dx%dx%dx%d %s N_ev=%d ultra-local 16-gamma loop (order FLOAT%d)" % (X + ("fp64" if prec == 8 else "fp32", nev, order))
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            if tj.get("workload") == workload:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "loop_trace_sites_per_sec", "value": value, "unit": "sites/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64" if prec == 8 else "f32", "data": "synthetic",
+        "config": {"workload": workload, "local_lattice": list(X), "n_ev": nev, "n_gamma": 16,
+                   "site_evecs_per_s": value * nev, "partition": "independent site blocks, one per rank"},
+        "roofline": {"bound": "hbm", "kernel": "loop_contract_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        base, cpu_loop, S = cpu_baseline(fields, sig, X, prec, order, a.cpu_seconds)
+        # the same sample on the GPU result: the checker agrees with what was just timed
+        g = loop.view(16, 2, V // 2)[:, :, :S].reshape(-1).cpu().numpy()
+        err = float(np.max(np.abs(g - cpu_loop)) / np.max(np.abs(cpu_loop)))
+        base["max_rel_err_gpu_vs_cpu_on_sample"] = err
+        out["cpu_baseline"] = base
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
