@@ -148,6 +148,29 @@ int mugiq_hip_perform_covariant_displacement_vector(const MugiqHipSpinorField *d
  * face_d: 2*12*faceCB complex elements of the field's precision, laid out as a ghost zone. */
 int mugiq_hip_pack_face(void *face_d, const MugiqHipSpinorField *src, int dim, int high, void *stream);
 
+/* Batched, multi-layer version for the fused path: for every eigenvector n < nVec and layer j < layers pack the
+ * face x[dim] = j (high = 0) or x[dim] = X[dim]-1-j (high = 1) into
+ * faces_d[n][j] = one ghost zone (2*12*faceCB complex), contiguous over (n, j) so one message carries them all. */
+int mugiq_hip_pack_face_layers(void *faces_d, const MugiqHipSpinorField *eVecs_h, int nVec, int dim, int high,
+                               int layers, void *stream);
+
+/* ---- fused displaced contraction (new; the fast form of lib/loop_mugiq.cpp:485-497) --------------------------- */
+/* For one displacement entry (dispDir, dispSign) and the lengths kValues_h[0..nK):
+ *   loopData_d[slot i][tid + V*iG] += sum_n (1/sigma_n) v_n^dag(x) G(iG) W_k(x) v_n(x +- k mu),  k = kValues_h[i]
+ * where W_k is the path-ordered link product, handed over as pathLinkFields_h[i] = device pointer to the field
+ * E_k = D^k E_0, E_0(x)(s,c) = delta_sc for s < 3 (a FLOAT2 spinor field with stride = volumeCB, pad 0, of the
+ * eigenvectors' precision) -- i.e. the output of k applications of
+ * mugiq_hip_perform_covariant_displacement_vector to E_0.  The displaced vectors are never materialised.
+ * Slots are 16*V complex apart.  If commDim[dispDir] != 0, ghostLayers_d holds `layers` >= max k face layers
+ * of every eigenvector received from the neighbour the displacement points to, laid out as
+ * mugiq_hip_pack_face_layers writes them (sign +: the forward neighbour's LOW layers; sign -: the backward
+ * neighbour's HIGH layers). */
+int mugiq_hip_displaced_loop_contraction_fused(void *loopData_d, const MugiqHipSpinorField *eVecs_h,
+                                               const double *sigma_h, int nVec, const void *const *pathLinkFields_h,
+                                               const int *kValues_h, int nK, int dispDir, int dispSign,
+                                               const int commDim[4], const void *ghostLayers_d, int layers,
+                                               void *stream);
+
 /* ---- a8  Fourier phase matrix -------------------------------------------------------------------------- */
 /* createPhaseMatrixGPU<Float>(phaseMatrix_d, momMatrix_h, locV3, Nmom, FTSign, localL, totalL)
  * lib/contract_wrappers.cu:50-77, kernel lib/mugiq_util_kernels.cu:3-35.  commCoord[4] replaces QUDA's
@@ -171,6 +194,105 @@ size_t mugiq_hip_momentum_projection_workspace(int locT, int nData, long long lo
 int mugiq_hip_momentum_projection(void *dataMom_d, const void *dataPosMP_d, const void *phaseMatrix_d,
                                   int locT, int nData, long long locV3, int Nmom, int precision,
                                   void *workspace_d, size_t workspace_bytes, void *stream);
+
+/* ==== host-side driver: the Loop_Mugiq / Displace classes of the reference ========================================= */
+
+/* include/enum_mugiq.h:35-41.  calcType is parsed but never read by the reference's live code; here it selects
+ * the execution plan: BASIC = the reference's own sequence (one displacement + one contraction launch per
+ * eigenvector and step, lib/loop_mugiq.cpp:478-503); OPT and BLAS = eigenvector-batched contraction and the
+ * fused displaced contraction (same results to rounding). */
+#define MUGIQ_HIP_LOOP_CALC_TYPE_BLAS 0
+#define MUGIQ_HIP_LOOP_CALC_TYPE_OPT_KERNEL 1
+#define MUGIQ_HIP_LOOP_CALC_TYPE_BASIC_KERNEL 2
+
+/* What Loop_Mugiq reads from QUDA's comm layer and MPI (lib/loop_mugiq.cpp:61-88,406-424) and what
+ * exchangeGhostVec does (lib/contract_wrappers.cu:166-169), as callbacks so the host program owns the
+ * transport (MPI in a MuGiq build; torch.distributed/RCCL in mugiq_amd; NULL comm = one process).
+ * All callbacks return 0 on success. */
+typedef struct MugiqHipComm_s {
+  void *ctx;
+  int rank, size;
+  int grid[4];  /* comm_dim(d): ranks along x,y,z,t */
+  int coord[4]; /* comm_coord(d) */
+  /* Send `bytes` from send_d to the neighbour at coord[dim]+dir (dir = +1 | -1, periodic) and receive `bytes`
+   * into recv_d from the neighbour at coord[dim]-dir.  Device pointers; ordered after prior work on `stream`
+   * and complete (or stream-ordered) before later work on `stream`. */
+  int (*sendrecv)(void *ctx, const void *send_d, void *recv_d, size_t bytes, int dim, int dir, void *stream);
+  /* MPI_Reduce(SUM) over the ranks sharing coord[3] onto the one with coord[0..2] == 0 (COMM_SPACE,
+   * lib/loop_mugiq.cpp:67,406).  Host buffers of n_real reals of `precision` bytes each. */
+  int (*reduce_space)(void *ctx, const void *send_h, void *recv_h, size_t n_real, int precision);
+  /* MPI_Gather over the ranks with coord[0..2] == 0, ordered by coord[3], root coord[3] == 0 (COMM_TIME,
+   * lib/loop_mugiq.cpp:81,420-422).  recv_h is significant on the root only. */
+  int (*gather_time)(void *ctx, const void *send_h, void *recv_h, size_t n_real_per_rank, int precision);
+  /* MPI_Bcast from world rank 0 (lib/loop_mugiq.cpp:424) */
+  int (*bcast)(void *ctx, void *buf_h, size_t n_real, int precision);
+} MugiqHipComm;
+
+/* MugiqLoopParam (include/mugiq.h:28-47) with C arrays instead of std::vector/std::string.
+ * gauge: the reference hands over host QDP-ordered links + a QudaGaugeParam and lets Displace build the
+ * border-extended device field (lib/displace.cpp:104-134); here the extended device field is the input
+ * (mugiq_amd builds it; see GaugeField).  May be NULL when doNonLocal == 0. */
+typedef struct MugiqHipLoopParam_s {
+  int Nmom;
+  const int *momMatrix; /* [Nmom][3] */
+  int FTSign;           /* LoopFTSign: -1 | +1 */
+  int calcType;         /* MUGIQ_HIP_LOOP_CALC_TYPE_* */
+  int writeMomSpaceHDF5;
+  int writePosSpaceHDF5;
+  int doMomProj;
+  int doNonLocal;
+  int nDispEntries;              /* disp_str.size() */
+  const char *const *disp_entry; /* e.g. "+z:1,8" */
+  const char *const *disp_str;   /* e.g. "+z" */
+  const int *disp_start;
+  const int *disp_stop;
+  const char *fname_mom_h5;
+  const char *fname_pos_h5;
+  const MugiqHipGaugeField *gauge;
+} MugiqHipLoopParam;
+
+/* Loop_Mugiq::LoopComputeParam + the element counts of allocateDataMemory
+ * (include/loop_mugiq.h:141-271, lib/loop_mugiq.cpp:101-109) */
+typedef struct MugiqHipLoopInfo_s {
+  int nDispEntries, nLoop, nData, Nmom, precision, field_order;
+  int localL[4], totalL[4];
+  int locT, totT;
+  long long locV4, locV3, totV3;
+  long long nElemPosLocPerLoop, nElemMomLocPerLoop, nElemMomTotPerLoop;
+  long long nElemPosLoc, nElemMomLoc, nElemMomTot, nElemPhMat;
+} MugiqHipLoopInfo;
+
+typedef struct MugiqHipLoop_s MugiqHipLoop;
+
+/* Loop_Mugiq::Loop_Mugiq(loopParams, eigsolve)  lib/loop_mugiq.cpp:6-59: takes what the class reads from
+ * Eigsolve_Mugiq as a friend -- eVecs[0..nEv) and eVals_sigma[0..nEv) (lib/loop_mugiq.cpp:442,479) -- sets up
+ * LoopComputeParam, allocates the data buffers, creates the phase matrix.  comm may be NULL (single process).
+ * The descriptors are copied; the eigenvector memory stays the caller's. */
+int mugiq_hip_loop_create(MugiqHipLoop **loop, const MugiqHipLoopParam *param, const MugiqHipSpinorField *eVecs_h,
+                          const double *eVals_sigma_h, int nEv, const MugiqHipComm *comm, void *stream);
+/* Loop_Mugiq::computeCoarseLoop()  lib/loop_mugiq.cpp:439-525 (position-space loops for the ultra-local case and
+ * every displacement entry, then performMomentumProjection :322-434 if doMomProj).  Synchronises `stream`. */
+int mugiq_hip_loop_compute(MugiqHipLoop *loop);
+int mugiq_hip_loop_get_info(const MugiqHipLoop *loop, MugiqHipLoopInfo *info);
+/* slot bookkeeping of entry id: (dir, sign, start, stop, nLoopPerEntry, nLoopOffset) -> out6[6] */
+int mugiq_hip_loop_get_entry(const MugiqHipLoop *loop, int id, int out6[6]);
+/* dataPos_d: [nLoop][16][V even-odd] complex, device.  dataPos (host) is copied on first request
+ * (the reference copies it unconditionally at lib/loop_mugiq.cpp:512). */
+const void *mugiq_hip_loop_data_pos_d(const MugiqHipLoop *loop);
+const void *mugiq_hip_loop_data_pos_h(MugiqHipLoop *loop);
+/* dataMom_bcast (host): per time-rank slabs of t + locT*ig + locT*16*iL + locT*16*nLoop*im, concatenated in
+ * coord[3] order (lib/loop_mugiq.cpp:415-424).  NULL before compute or without doMomProj. */
+const void *mugiq_hip_loop_data_mom_bcast_h(const MugiqHipLoop *loop);
+/* Loop_Mugiq::~Loop_Mugiq */
+int mugiq_hip_loop_destroy(MugiqHipLoop *loop);
+
+/* ---- user syntax (tests/loop.cpp:607-705) -------------------------------------------------------------------------- */
+/* Parse "+z:1,8;-x:3;+y:2,5".  Returns the number of entries (<= max_entries) or a negative MugiqHipStatus.
+ * disp_str_out: max_entries x 4 chars ("+z\0"); start/stop as in setLoopParam. */
+int mugiq_hip_parse_displace_entry_string(const char *entry_string, int max_entries, char *disp_str_out,
+                                          int *disp_start_out, int *disp_stop_out);
+/* Displace::WhichDisplaceFlag/Dir/Sign (lib/displace.cpp:137-202): "+x".."-t" -> dir, sign; non-zero if unparsable */
+int mugiq_hip_parse_displacement(const char *disp_str, int *dir_out, int *sign_out);
 
 #ifdef __cplusplus
 }

@@ -11,9 +11,14 @@ from .fields import SpinorField, GaugeField, FLOAT2, FLOAT4  # noqa: E402
 from .operators import (  # noqa: E402
     copyGammaCoeffStructToSymbol, copyGammaMapStructToSymbol, gammaTables, GammaName,
     performLoopContraction, performLoopContractionBatched, performCovariantDisplacementVector, packFace,
-    createPhaseMatrixGPU, convertIdxOrder_mapGamma, momentumProjection,
+    createPhaseMatrixGPU, convertIdxOrder_mapGamma, momentumProjection, packFaceLayers, displacedLoopContractionFused,
     DispDir, DispSignMinus, DispSignPlus, LOOP_FT_SIGN_MINUS, LOOP_FT_SIGN_PLUS, DisplaceFlagArray,
 )
 from ._lib import MugiqHipError, LIB_PATH  # noqa: E402
+from .loop import (  # noqa: E402
+    MugiqLoopParam, Loop_Mugiq, parseDisplaceEntryString, parseDisplacement, read_momenta_file,
+    LOOP_CALC_TYPE_BLAS, LOOP_CALC_TYPE_OPT_KERNEL, LOOP_CALC_TYPE_BASIC_KERNEL,
+)
+from .comm import GridComm  # noqa: E402
 
 __all__ = [n for n in dir() if not n.startswith("_")]

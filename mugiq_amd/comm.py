@@ -1,0 +1,180 @@
+"""Process-grid communication for the loop engine over torch.distributed (backend "nccl" = RCCL over xGMI on
+MI355X; "gloo" on CPU, or with device buffers staged through the host).
+
+This is the role QUDA's comm layer + MPI play in the reference:
+  * the 4-d process grid, comm_dim / comm_coord (tests/loop.cpp:781; include/contract_util.cuh:64,89);
+  * the nearest-neighbour face exchange of ColorSpinorField::exchangeGhost (lib/contract_wrappers.cu:166-169);
+  * the COMM_SPACE / COMM_TIME sub-communicators and MPI_Reduce / MPI_Gather / MPI_Bcast of
+    Loop_Mugiq::setupComms + performMomentumProjection (lib/loop_mugiq.cpp:61-88, 406-424).
+One process per GPU.  The rank <-> coordinate map is QUDA's default (t runs fastest).
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+class _DevPtr:
+    """Expose a raw device pointer to torch through __cuda_array_interface__ (no copy, no ownership)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def device_bytes(ptr, nbytes, device):
+    return torch.as_tensor(_DevPtr(ptr, nbytes), device=device)
+
+
+def host_array(ptr, n_real, precision):
+    ct = ctypes.c_double if precision == 8 else ctypes.c_float
+    return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ct)), shape=(int(n_real),))
+
+
+class GridComm:
+    def __init__(self, grid, device=None):
+        """grid = ranks along (x, y, z, t).  torch.distributed must be initialised; every rank must construct this
+        (it creates the sub-groups collectively)."""
+        self.grid = tuple(int(g) for g in grid)
+        self.size = dist.get_world_size()
+        self.rank = dist.get_rank()
+        assert int(np.prod(self.grid)) == self.size, "process grid %s does not match world size %d" % (self.grid, self.size)
+        self.coord = self.coords_of(self.rank)
+        self.backend = dist.get_backend()
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        # COMM_SPACE: ranks with equal t-coordinate, root = the one with x=y=z=0 (lowest world rank of the group)
+        # COMM_TIME : ranks with x=y=z=0, ordered by t, root t=0                      lib/loop_mugiq.cpp:61-88
+        self.space_group, self.space_root = None, None
+        for t in range(self.grid[3]):
+            ranks = [r for r in range(self.size) if self.coords_of(r)[3] == t]
+            g = dist.new_group(ranks)
+            if self.coord[3] == t:
+                self.space_group, self.space_root = g, min(ranks)
+        self.time_ranks = [self.rank_of((0, 0, 0, t)) for t in range(self.grid[3])]
+        self.time_group = dist.new_group(self.time_ranks)
+        self.is_time_process = self.coord[:3] == (0, 0, 0)
+        self._cb = None
+
+    # ---- topology (QUDA's comm_rank_from_coords: x slowest, t fastest) --------------------------------------
+    def coords_of(self, rank):
+        gx, gy, gz, gt = self.grid
+        t = rank % gt
+        z = (rank // gt) % gz
+        y = (rank // (gt * gz)) % gy
+        x = rank // (gt * gz * gy)
+        return (x, y, z, t)
+
+    def rank_of(self, c):
+        gx, gy, gz, gt = self.grid
+        return ((c[0] * gy + c[1]) * gz + c[2]) * gt + c[3]
+
+    def comm_dim_partitioned(self, d):
+        return 1 if self.grid[d] > 1 else 0
+
+    def neighbour(self, dim, direction):
+        c = list(self.coord)
+        c[dim] = (c[dim] + direction) % self.grid[dim]
+        return self.rank_of(c)
+
+    # ---- halo -------------------------------------------------------------------------------------------------
+    def sendrecv(self, send, recv, dim, direction):
+        """Send `send` to the neighbour at coord[dim]+direction, receive `recv` from coord[dim]-direction.
+        Tensors may live on the GPU; with a CPU-only backend (gloo) they are staged through host memory."""
+        dst, src = self.neighbour(dim, direction), self.neighbour(dim, -direction)
+        stage = self.backend == "gloo" and send.is_cuda
+        s = send.cpu() if stage else send
+        r = torch.empty_like(recv, device="cpu") if stage else recv
+        if dst == self.rank:                      # grid of 1 in this dim (not called by the driver) -> periodic copy
+            r.copy_(s)
+        else:
+            ops = [dist.P2POp(dist.isend, s, dst), dist.P2POp(dist.irecv, r, src)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if stage:
+            recv.copy_(r)
+
+    # ---- FT reduction (host-side payloads, tiny) -----------------------------------------------------------------
+    def _wire(self, t):
+        return t.to(self.device) if self.backend == "nccl" else t
+
+    def reduce_space(self, send, recv):
+        """recv = sum over the ranks sharing my t-coordinate of send, on the group's time process only."""
+        t = self._wire(send.clone())
+        dist.reduce(t, dst=self.space_root, op=dist.ReduceOp.SUM, group=self.space_group)
+        if self.rank == self.space_root:
+            recv.copy_(t.cpu())
+
+    def gather_time(self, send, recv):
+        """Concatenate the time processes' buffers in t order into recv (significant on the t=0 time process)."""
+        if not self.is_time_process:
+            return
+        parts = [torch.empty_like(self._wire(send)) for _ in self.time_ranks]
+        dist.all_gather(parts, self._wire(send.clone()), group=self.time_group)
+        if self.coord[3] == 0:
+            recv.copy_(torch.cat([p.cpu() for p in parts]))
+
+    def bcast(self, buf):
+        t = self._wire(buf.clone() if self.backend == "nccl" else buf)
+        dist.broadcast(t, src=0)
+        if self.backend == "nccl":
+            buf.copy_(t.cpu())
+
+    # ---- C callbacks for the driver (MugiqHipComm) ----------------------------------------------------------------
+    def c_struct(self):
+        if self._cb is not None:
+            return self._cb[0]
+        SENDRECV = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                    ctypes.c_int, ctypes.c_int, ctypes.c_void_p)
+        REDUCE = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int)
+        BCAST = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int)
+
+        def guard(fn):
+            def wrapped(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception as e:  # never let an exception cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return wrapped
+
+        def c_sendrecv(ctx, send_d, recv_d, nbytes, dim, direction, stream):
+            # the driver enqueued the pack kernel on `stream`; torch's collectives order against torch's
+            # current stream, which mugiq_amd uses for every launch
+            s = device_bytes(send_d, nbytes, self.device)
+            r = device_bytes(recv_d, nbytes, self.device)
+            if self.backend == "gloo":
+                torch.cuda.current_stream().synchronize()
+            self.sendrecv(s, r, dim, direction)
+
+        def c_reduce(ctx, send_h, recv_h, n, prec):
+            s = torch.from_numpy(host_array(send_h, n, prec))
+            r = torch.from_numpy(host_array(recv_h, n, prec))
+            self.reduce_space(s, r)
+
+        def c_gather(ctx, send_h, recv_h, n, prec):
+            s = torch.from_numpy(host_array(send_h, n, prec))
+            r = torch.from_numpy(host_array(recv_h, n * self.grid[3], prec))
+            self.gather_time(s, r)
+
+        def c_bcast(ctx, buf_h, n, prec):
+            self.bcast(torch.from_numpy(host_array(buf_h, n, prec)))
+
+        class CComm(ctypes.Structure):
+            _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("size", ctypes.c_int),
+                        ("grid", ctypes.c_int * 4), ("coord", ctypes.c_int * 4),
+                        ("sendrecv", SENDRECV), ("reduce_space", REDUCE), ("gather_time", REDUCE), ("bcast", BCAST)]
+
+        fns = (SENDRECV(guard(c_sendrecv)), REDUCE(guard(c_reduce)), REDUCE(guard(c_gather)), BCAST(guard(c_bcast)))
+        c = CComm()
+        c.ctx = None
+        c.rank, c.size = self.rank, self.size
+        for d in range(4):
+            c.grid[d] = self.grid[d]
+            c.coord[d] = self.coord[d]
+        c.sendrecv, c.reduce_space, c.gather_time, c.bcast = fns
+        self._cb = (c, fns)          # keep the callbacks alive
+        return c

@@ -1,0 +1,573 @@
+// Host-side driver: the Loop_Mugiq<Float,order> and Displace<Float,order> classes of the reference
+// (include/loop_mugiq.h, lib/loop_mugiq.cpp, include/displace.h, lib/displace.cpp) over the C-ABI operators.
+//
+// What is kept: LoopComputeParam's slot bookkeeping (include/loop_mugiq.h:221-256), the buffer set and element
+// counts of allocateDataMemory (lib/loop_mugiq.cpp:101-158), the loop nest of computeCoarseLoop (:455-509), the
+// displacement string table (include/displace.h:21, lib/displace.cpp:137-223), and the sequence of
+// performMomentumProjection (:343-424: reorder -> GEMM -> D2H -> reduce over space ranks -> gather over time ranks
+// -> broadcast).  What is dropped: the per-eigenvector field copies (:483,487,501), blas::zero + the two copies
+// of swapAuxDispVec (lib/displace.cpp:47-59), the per-launch cudaMalloc/cudaMemcpy/cudaFree/cudaDeviceSynchronize
+// (lib/contract_wrappers.cu:93-114), and the exchange of all four faces in both directions per step.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "internal.h"
+
+namespace mugiq {
+
+static const char *kDisplaceFlagArray[8] = {"+x", "-x", "+y", "-y", "+z", "-z", "+t", "-t"};  // include/displace.h:21
+
+// Displace::WhichDisplaceFlag / WhichDisplaceDir / WhichDisplaceSign  (lib/displace.cpp:137-202):
+// flag = index in the table; dir = flag/2; even flags are "+" (DispSignPlus = 1), odd "-" (DispSignMinus = 0)
+static int parse_displacement(const char *s, int *dir, int *sign) {
+  for (int i = 0; i < 8; i++)
+    if (s && strcmp(s, kDisplaceFlagArray[i]) == 0) {
+      *dir = i / 2;
+      *sign = (i % 2 == 0) ? MUGIQ_HIP_DISP_SIGN_PLUS : MUGIQ_HIP_DISP_SIGN_MINUS;
+      return MUGIQ_HIP_SUCCESS;
+    }
+  return set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "WhichDisplaceFlag: Cannot parse given displacement string = %s.",
+                   s ? s : "(null)");
+}
+
+}  // namespace mugiq
+
+using namespace mugiq;
+
+struct MugiqHipLoop_s {
+  // ---- LoopComputeParam (include/loop_mugiq.h:141-271)
+  int Nmom = 0, FTSign = 1, calcType = MUGIQ_HIP_LOOP_CALC_TYPE_OPT_KERNEL;
+  bool doMomProj = false, doNonLocal = false;
+  std::vector<int> momMatrix;
+  int localL[4], totalL[4];
+  int volumeCB = 0, locT = 0, totT = 0;
+  long long locV4 = 1, locV3 = 1, totV3 = 1;
+  std::vector<std::string> dispEntry, dispString;
+  std::vector<int> dispStart, dispStop, nLoopPerEntry, nLoopOffset, dispDir, dispSign;
+  int nDispEntries = 0, nLoop = 0, nData = 0;
+  std::string fnameMom, fnamePos;
+  bool writeMom = false, writePos = false;
+  // ---- inputs
+  std::vector<MugiqHipSpinorField> eVecs;
+  std::vector<double> sigma;
+  int nEv = 0, precision = 8, order = 2;
+  MugiqHipGaugeField gauge;
+  bool haveGauge = false;
+  MugiqHipComm comm;
+  bool haveComm = false;
+  int commDim[4] = {0, 0, 0, 0};
+  hipStream_t stream = nullptr;
+  // ---- data buffers (include/loop_mugiq.h:49-57, lib/loop_mugiq.cpp:101-158)
+  long long nElemMomTotPerLoop = 0, nElemMomLocPerLoop = 0, nElemPosLocPerLoop = 0;
+  long long nElemMomTot = 0, nElemMomLoc = 0, nElemPosLoc = 0, nElemPhMat = 0;
+  void *dataPos_d = nullptr, *dataPosMP_d = nullptr, *dataMom_d = nullptr, *phaseMatrix_d = nullptr;
+  void *dataPos = nullptr, *dataMom_h = nullptr, *dataMom = nullptr, *dataMom_bcast = nullptr;
+  bool dataPosCopied = false, momProjDone = false, computed = false;
+  // ---- displacement scratch (Displace::auxDispVec and friends)
+  std::vector<void *> scratch;  // device allocations freed in the destructor
+
+  size_t cplxBytes() const { return 2 * (size_t)precision; }
+};
+
+namespace mugiq {
+
+static int dev_alloc(MugiqHipLoop *lp, void **p, size_t bytes, bool zero) {
+  MUGIQ_CHECK_HIP(hipMalloc(p, bytes ? bytes : 16));
+  if (zero) MUGIQ_CHECK_HIP(hipMemsetAsync(*p, 0, bytes, lp->stream));
+  return MUGIQ_HIP_SUCCESS;
+}
+
+// A FLOAT2, pad-0 scratch field with the eigenvectors' geometry (+ room for both depth-1 ghost zones of `dim`).
+static int make_scratch_field(MugiqHipLoop *lp, MugiqHipSpinorField *f, int order) {
+  *f = lp->eVecs[0];
+  f->field_order = order;
+  f->stride = lp->volumeCB;
+  f->parity_offset = (int64_t)12 * lp->volumeCB;
+  for (int d = 0; d < 4; d++) f->ghost[d][0] = f->ghost[d][1] = nullptr;
+  void *p = nullptr;
+  int st = dev_alloc(lp, &p, (size_t)2 * f->parity_offset * lp->cplxBytes(), true);
+  if (st) return st;
+  lp->scratch.push_back(p);
+  f->data = p;
+  return MUGIQ_HIP_SUCCESS;
+}
+
+// exchangeGhostVec for ONE face: the face the displacement (dir, sign) reads (lib/contract_wrappers.cu:166-169
+// exchanges all partitioned dims in both directions).
+static int exchange_face(MugiqHipLoop *lp, MugiqHipSpinorField *src, int dir, int sign, void *send_d, void *recv_d) {
+  const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;  // sign +: my LOW face feeds the backward neighbour
+  int st = mugiq_hip_pack_face(send_d, src, dir, high, lp->stream);
+  if (st) return st;
+  const size_t bytes = (size_t)24 * (lp->volumeCB / lp->localL[dir]) * lp->cplxBytes();
+  st = lp->comm.sendrecv(lp->comm.ctx, send_d, recv_d, bytes, dir, high ? +1 : -1, lp->stream);
+  if (st) return set_error(MUGIQ_HIP_ERROR_HIP, "halo sendrecv callback failed with status %d", st);
+  src->ghost[dir][sign == MUGIQ_HIP_DISP_SIGN_PLUS ? 1 : 0] = recv_d;
+  return MUGIQ_HIP_SUCCESS;
+}
+
+// ---- the reference's own plan: one displacement + one contraction launch per eigenvector and step -----------
+static int entry_basic(MugiqHipLoop *lp, int id, void *slot0) {
+  const int dir = lp->dispDir[id], sign = lp->dispSign[id];
+  const bool part = lp->commDim[dir] != 0;
+  MugiqHipSpinorField aux[2];
+  int st;
+  for (int i = 0; i < 2; i++)
+    if ((st = make_scratch_field(lp, &aux[i], lp->order))) return st;
+  void *send_d = nullptr, *recv_d = nullptr;
+  if (part) {
+    const size_t fb = (size_t)24 * (lp->volumeCB / lp->localL[dir]) * lp->cplxBytes();
+    if ((st = dev_alloc(lp, &send_d, fb, false))) return st;
+    lp->scratch.push_back(send_d);
+    if ((st = dev_alloc(lp, &recv_d, fb, false))) return st;
+    lp->scratch.push_back(recv_d);
+  }
+  const size_t slotBytes = (size_t)lp->nElemPosLocPerLoop * lp->cplxBytes();
+  for (int n = 0; n < lp->nEv; n++) {  // lib/loop_mugiq.cpp:478
+    MugiqHipSpinorField cur = lp->eVecs[n];
+    int dispCount = 0;
+    for (int idisp = 1; idisp <= lp->dispStop[id]; idisp++) {  // :489
+      MugiqHipSpinorField *dst = &aux[idisp & 1];
+      if (part && (st = exchange_face(lp, &cur, dir, sign, send_d, recv_d))) return st;
+      if ((st = mugiq_hip_perform_covariant_displacement_vector(dst, &cur, &lp->gauge, dir, sign, lp->commDim, lp->stream)))
+        return st;  // Displace::doVectorDisplacement, lib/displace.cpp:55-67
+      cur = *dst;
+      if (idisp >= lp->dispStart[id] && idisp <= lp->dispStop[id]) {  // :491-496
+        void *slot = static_cast<char *>(slot0) + slotBytes * dispCount;
+        if ((st = mugiq_hip_perform_loop_contraction(slot, &lp->eVecs[n], &cur, lp->sigma[n], lp->stream))) return st;
+        dispCount++;
+      }
+    }
+  }
+  return MUGIQ_HIP_SUCCESS;
+}
+
+// ---- the fused plan -------------------------------------------------------------------------------------------
+static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
+  const int dir = lp->dispDir[id], sign = lp->dispSign[id];
+  const bool part = lp->commDim[dir] != 0;
+  const int stop = lp->dispStop[id], start = lp->dispStart[id];
+  int st;
+  if (part && stop > lp->localL[dir])
+    return set_error(MUGIQ_HIP_ERROR_UNSUPPORTED,
+                     "displacement length %d exceeds the local extent %d of a partitioned dimension; use calcType BASIC", stop,
+                     lp->localL[dir]);
+  // path-ordered link products W_k as E_k = D^k E_0, E_0(x)(s,c) = delta_sc, s < 3
+  std::vector<MugiqHipSpinorField> E(stop + 1);
+  for (int k = 0; k <= stop; k++)
+    if ((st = make_scratch_field(lp, &E[k], 2))) return st;
+  {
+    const size_t one = lp->cplxBytes();
+    std::vector<unsigned char> plane((size_t)lp->volumeCB * one, 0);
+    for (int i = 0; i < lp->volumeCB; i++) {
+      if (lp->precision == 8) reinterpret_cast<double *>(plane.data())[2 * i] = 1.0;
+      else reinterpret_cast<float *>(plane.data())[2 * i] = 1.0f;
+    }
+    for (int pty = 0; pty < 2; pty++)
+      for (int s = 0; s < 3; s++) {
+        char *dstp = static_cast<char *>(E[0].data) + ((size_t)pty * E[0].parity_offset + (size_t)(s * 3 + s) * lp->volumeCB) * one;
+        MUGIQ_CHECK_HIP(hipMemcpyAsync(dstp, plane.data(), plane.size(), hipMemcpyHostToDevice, lp->stream));
+      }
+    MUGIQ_CHECK_HIP(hipStreamSynchronize(lp->stream));  // `plane` leaves scope
+  }
+  void *send_d = nullptr, *recv_d = nullptr;
+  const int faceCB = lp->volumeCB / lp->localL[dir];
+  if (part) {
+    const size_t fb = (size_t)24 * faceCB * lp->cplxBytes();
+    if ((st = dev_alloc(lp, &send_d, fb, false))) return st;
+    lp->scratch.push_back(send_d);
+    if ((st = dev_alloc(lp, &recv_d, fb, false))) return st;
+    lp->scratch.push_back(recv_d);
+  }
+  for (int k = 1; k <= stop; k++) {
+    if (part && (st = exchange_face(lp, &E[k - 1], dir, sign, send_d, recv_d))) return st;
+    if ((st = mugiq_hip_perform_covariant_displacement_vector(&E[k], &E[k - 1], &lp->gauge, dir, sign, lp->commDim, lp->stream)))
+      return st;
+  }
+  std::vector<const void *> links;
+  std::vector<int> kv;
+  for (int k = start; k <= stop; k++) {
+    links.push_back(E[k].data);
+    kv.push_back(k);
+  }
+  // eigenvector blocks: bounded by the ghost-layer buffers when the dimension is partitioned
+  int nb = lp->nEv;
+  void *gsend = nullptr, *grecv = nullptr;
+  size_t perVec = 0;
+  if (part) {
+    perVec = (size_t)stop * 24 * faceCB * lp->cplxBytes();
+    const size_t budget = (size_t)4 << 30;  // 4 GiB per direction buffer
+    nb = (int)std::max<size_t>(1, std::min<size_t>((size_t)lp->nEv, budget / perVec));
+    if ((st = dev_alloc(lp, &gsend, perVec * nb, false))) return st;
+    lp->scratch.push_back(gsend);
+    if ((st = dev_alloc(lp, &grecv, perVec * nb, false))) return st;
+    lp->scratch.push_back(grecv);
+  }
+  for (int n0 = 0; n0 < lp->nEv; n0 += nb) {
+    const int nv = std::min(nb, lp->nEv - n0);
+    if (part) {
+      const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
+      if ((st = mugiq_hip_pack_face_layers(gsend, &lp->eVecs[n0], nv, dir, high, stop, lp->stream))) return st;
+      st = lp->comm.sendrecv(lp->comm.ctx, gsend, grecv, perVec * nv, dir, high ? +1 : -1, lp->stream);
+      if (st) return set_error(MUGIQ_HIP_ERROR_HIP, "halo sendrecv callback failed with status %d", st);
+    }
+    if ((st = mugiq_hip_displaced_loop_contraction_fused(slot0, &lp->eVecs[n0], &lp->sigma[n0], nv, links.data(), kv.data(),
+                                                         (int)kv.size(), dir, sign, lp->commDim, grecv, stop, lp->stream)))
+      return st;
+  }
+  return MUGIQ_HIP_SUCCESS;
+}
+
+static void free_scratch(MugiqHipLoop *lp) {
+  for (void *p : lp->scratch) (void)hipFree(p);
+  lp->scratch.clear();
+}
+
+// Loop_Mugiq::performMomentumProjection  lib/loop_mugiq.cpp:322-434
+static int momentum_projection(MugiqHipLoop *lp) {
+  if (lp->momProjDone) return set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "performMomentumProjection: Not supposed to be called more than once!!");
+  int st;
+  if ((st = mugiq_hip_convert_idx_order_map_gamma(lp->dataPosMP_d, lp->dataPos_d, lp->nData, lp->nLoop, 2, lp->volumeCB,
+                                                  lp->localL, lp->precision, lp->stream)))  // :343-344
+    return st;
+  if ((st = mugiq_hip_momentum_projection(lp->dataMom_d, lp->dataPosMP_d, lp->phaseMatrix_d, lp->locT, lp->nData, lp->locV3,
+                                          lp->Nmom, lp->precision, nullptr, 0, lp->stream)))  // :363-378
+    return st;
+  const size_t locBytes = (size_t)lp->nElemMomLoc * lp->cplxBytes();
+  MUGIQ_CHECK_HIP(hipMemcpyAsync(lp->dataMom_h, lp->dataMom_d, locBytes, hipMemcpyDeviceToHost, lp->stream));  // :386
+  MUGIQ_CHECK_HIP(hipStreamSynchronize(lp->stream));
+  if (lp->haveComm && lp->comm.size > 1) {
+    const size_t nReal = 2 * (size_t)lp->nElemMomLoc;
+    if ((st = lp->comm.reduce_space(lp->comm.ctx, lp->dataMom_h, lp->dataMom, nReal, lp->precision)))  // :406
+      return set_error(MUGIQ_HIP_ERROR_HIP, "reduce_space callback failed with status %d", st);
+    if ((st = lp->comm.gather_time(lp->comm.ctx, lp->dataMom, lp->dataMom_bcast, nReal, lp->precision)))  // :420-422
+      return set_error(MUGIQ_HIP_ERROR_HIP, "gather_time callback failed with status %d", st);
+    if ((st = lp->comm.bcast(lp->comm.ctx, lp->dataMom_bcast, 2 * (size_t)lp->nElemMomTot, lp->precision)))  // :424
+      return set_error(MUGIQ_HIP_ERROR_HIP, "bcast callback failed with status %d", st);
+  } else {
+    memcpy(lp->dataMom, lp->dataMom_h, locBytes);
+    memcpy(lp->dataMom_bcast, lp->dataMom, locBytes);
+  }
+  lp->momProjDone = true;
+  return MUGIQ_HIP_SUCCESS;
+}
+
+}  // namespace mugiq
+
+extern "C" {
+
+int mugiq_hip_parse_displacement(const char *disp_str, int *dir_out, int *sign_out) {
+  MUGIQ_REQUIRE(dir_out && sign_out, "mugiq_hip_parse_displacement: NULL output");
+  return parse_displacement(disp_str, dir_out, sign_out);
+}
+
+// tests/loop.cpp:607-705 (ParseDispEntry with ';' and ':', ParseDispLimits with ',')
+int mugiq_hip_parse_displace_entry_string(const char *entry_string, int max_entries, char *disp_str_out, int *disp_start_out,
+                                          int *disp_stop_out) {
+  if (!entry_string || !disp_str_out || !disp_start_out || !disp_stop_out)
+    return -set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "setLoopParam: NULL argument");
+  std::string all(entry_string);
+  if (all.empty()) return -set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "Got option '--loop-do-nonlocal yes' but option --displace-entry-string is not set!");
+  int n = 0;
+  size_t pos = 0;
+  while (true) {
+    size_t semi = all.find(';', pos);
+    std::string entry = all.substr(pos, semi == std::string::npos ? std::string::npos : semi - pos);
+    size_t colon = entry.find(':');
+    if (colon == std::string::npos || entry.find(':', colon + 1) != std::string::npos)
+      return -set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT,
+                        "Displacement entry %d has the Wrong format. Example of good entries: +z:1,8 , +x:3", n);
+    std::string dstr = entry.substr(0, colon), lim = entry.substr(colon + 1);
+    std::vector<int> lims;
+    size_t lp = 0;
+    while (true) {
+      size_t comma = lim.find(',', lp);
+      std::string tok = lim.substr(lp, comma == std::string::npos ? std::string::npos : comma - lp);
+      char *end = nullptr;
+      long v = strtol(tok.c_str(), &end, 10);
+      if (tok.empty() || end == tok.c_str())
+        return -set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "Wrong format of displacement entry %d. Example of good entries: +z:1,8 , +x:3", n);
+      lims.push_back((int)v);
+      if (comma == std::string::npos) break;
+      lp = comma + 1;
+    }
+    if (lims.empty() || lims.size() > 2)
+      return -set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "Wrong format of displacement entry %d. Example of good entries: +z:1,8 , +x:3", n);
+    if (n >= max_entries) return -set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "more than %d displacement entries", max_entries);
+    if (dstr.size() > 3) return -set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "displacement string '%s' too long", dstr.c_str());
+    strncpy(disp_str_out + 4 * n, dstr.c_str(), 4);
+    disp_str_out[4 * n + 3] = '\0';
+    disp_start_out[n] = lims[0];
+    disp_stop_out[n] = lims.size() == 2 ? lims[1] : lims[0];
+    n++;
+    if (semi == std::string::npos) break;
+    pos = semi + 1;
+  }
+  return n;
+}
+
+int mugiq_hip_loop_create(MugiqHipLoop **out, const MugiqHipLoopParam *p, const MugiqHipSpinorField *eVecs_h,
+                          const double *eVals_sigma_h, int nEv, const MugiqHipComm *comm, void *stream) {
+  const char *who = "Loop_Mugiq";
+  MUGIQ_REQUIRE(out && p && eVecs_h && eVals_sigma_h, "%s: NULL argument", who);
+  MUGIQ_REQUIRE(nEv >= 1, "%s: nEv = %d must be >= 1", who, nEv);
+  *out = nullptr;
+  int st;
+  for (int n = 0; n < nEv; n++) {
+    if ((st = validate_spinor(&eVecs_h[n], who, "eVecs"))) return st;
+    MUGIQ_REQUIRE(same_geometry(eVecs_h[n], eVecs_h[0]), "%s: eigenvector %d differs in precision, order or geometry from eVecs[0]", who, n);
+    MUGIQ_REQUIRE(eVals_sigma_h[n] != 0.0, "%s: eVals_sigma[%d] is zero", who, n);
+  }
+  MugiqHipLoop *lp = new MugiqHipLoop_s();
+  auto fail = [&](int code) {
+    mugiq_hip_loop_destroy(lp);
+    return code;
+  };
+  lp->stream = static_cast<hipStream_t>(stream);
+  lp->eVecs.assign(eVecs_h, eVecs_h + nEv);
+  lp->sigma.assign(eVals_sigma_h, eVals_sigma_h + nEv);
+  lp->nEv = nEv;
+  lp->precision = eVecs_h[0].precision;
+  lp->order = eVecs_h[0].field_order;
+  lp->volumeCB = eVecs_h[0].volumeCB;
+  if (comm) {
+    lp->comm = *comm;
+    lp->haveComm = true;
+    long long prod = 1;
+    for (int d = 0; d < 4; d++) {
+      if (comm->grid[d] < 1 || comm->coord[d] < 0 || comm->coord[d] >= comm->grid[d]) {
+        set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "%s: invalid comm grid/coord in dim %d", who, d);
+        return fail(MUGIQ_HIP_ERROR_INVALID_ARGUMENT);
+      }
+      lp->commDim[d] = comm->grid[d] > 1;
+      prod *= comm->grid[d];
+    }
+    if (prod != comm->size || (comm->size > 1 && (!comm->sendrecv || !comm->reduce_space || !comm->gather_time || !comm->bcast))) {
+      set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "%s: comm grid does not match comm size %d, or a callback is NULL", who, comm->size);
+      return fail(MUGIQ_HIP_ERROR_INVALID_ARGUMENT);
+    }
+  }
+  // ---- LoopComputeParam constructor, include/loop_mugiq.h:185-261
+  lp->Nmom = p->Nmom;
+  lp->FTSign = p->FTSign;
+  lp->calcType = p->calcType;
+  lp->doMomProj = p->doMomProj != 0;
+  lp->doNonLocal = p->doNonLocal != 0;
+  lp->writeMom = p->writeMomSpaceHDF5 != 0;
+  lp->writePos = p->writePosSpaceHDF5 != 0;
+  lp->fnameMom = p->fname_mom_h5 ? p->fname_mom_h5 : "";
+  lp->fnamePos = p->fname_pos_h5 ? p->fname_pos_h5 : "";
+  for (int i = 0; i < 4; i++) {
+    lp->localL[i] = eVecs_h[0].X[i];
+    lp->totalL[i] = lp->localL[i] * (lp->haveComm ? lp->comm.grid[i] : 1);
+    lp->locV4 *= lp->localL[i];
+    if (i < 3) {
+      lp->locV3 *= lp->localL[i];
+      lp->totV3 *= lp->totalL[i];
+    }
+  }
+  lp->locT = lp->localL[3];
+  lp->totT = lp->totalL[3];
+  if (lp->doMomProj) {
+    if (p->Nmom < 1 || !p->momMatrix || (p->FTSign != 1 && p->FTSign != -1)) {
+      set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "%s: doMomProj needs Nmom >= 1, a momentum matrix and FTSign = +-1 (Loop FT sign is undefined/unsupported)", who);
+      return fail(MUGIQ_HIP_ERROR_INVALID_ARGUMENT);
+    }
+    lp->momMatrix.assign(p->momMatrix, p->momMatrix + 3 * (size_t)p->Nmom);
+  }
+  if (lp->doNonLocal) {
+    lp->nDispEntries = p->nDispEntries;
+    if (p->nDispEntries < 0 || (p->nDispEntries > 0 && (!p->disp_str || !p->disp_start || !p->disp_stop))) {
+      set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "Displacement string length not compatible with displacement limits length");
+      return fail(MUGIQ_HIP_ERROR_INVALID_ARGUMENT);
+    }
+    for (int id = 0; id < lp->nDispEntries; id++) {
+      lp->dispEntry.push_back(p->disp_entry && p->disp_entry[id] ? p->disp_entry[id] : "");
+      lp->dispString.push_back(p->disp_str[id] ? p->disp_str[id] : "");
+      int a = p->disp_start[id], b = p->disp_stop[id];
+      if (a > b) std::swap(a, b);  // "Stop length is smaller than Start length ... Will switch lengths!"  :234-239
+      if (a < 1) {
+        set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "%s: displacement lengths must be >= 1 (entry %d: %d)", who, id, a);
+        return fail(MUGIQ_HIP_ERROR_INVALID_ARGUMENT);
+      }
+      lp->dispStart.push_back(a);
+      lp->dispStop.push_back(b);
+      lp->nLoopPerEntry.push_back(b - a + 1);
+      lp->nLoop += b - a + 1;
+      int osum = 1;  // start with ultra-local
+      for (int is = 0; is < id; is++) osum += lp->nLoopPerEntry[is];
+      lp->nLoopOffset.push_back(osum);
+      int dir, sign;
+      if ((st = parse_displacement(lp->dispString[id].c_str(), &dir, &sign))) return fail(st);  // Displace::setupDisplacement
+      lp->dispDir.push_back(dir);
+      lp->dispSign.push_back(sign);
+    }
+    lp->nLoop += 1;  // Don't forget ultra-local case!!
+    if (lp->nDispEntries > 0) {
+      if (!p->gauge) {
+        set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "%s: doNonLocal needs the (extended) gauge field for the displacements", who);
+        return fail(MUGIQ_HIP_ERROR_INVALID_ARGUMENT);
+      }
+      lp->gauge = *p->gauge;
+      lp->haveGauge = true;
+      for (int d = 0; d < 4; d++)
+        if (lp->commDim[d] && lp->gauge.R[d] < 1) {
+          set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "%s: dim %d is partitioned but the gauge border R[%d] = %d (the reference uses 2, lib/displace.cpp:16)", who, d, d, lp->gauge.R[d]);
+          return fail(MUGIQ_HIP_ERROR_INVALID_ARGUMENT);
+        }
+    }
+  } else {
+    lp->nDispEntries = 0;
+    lp->nLoop = 1;
+  }
+  lp->nData = lp->nLoop * 16;
+  // ---- allocateDataMemory, lib/loop_mugiq.cpp:101-158
+  lp->nElemMomTotPerLoop = 16LL * lp->Nmom * lp->totT;
+  lp->nElemMomLocPerLoop = 16LL * lp->Nmom * lp->locT;
+  lp->nElemPosLocPerLoop = 16LL * lp->locV4;
+  lp->nElemMomTot = lp->nElemMomTotPerLoop * lp->nLoop;
+  lp->nElemMomLoc = lp->nElemMomLocPerLoop * lp->nLoop;
+  lp->nElemPosLoc = lp->nElemPosLocPerLoop * lp->nLoop;
+  lp->nElemPhMat = (long long)lp->Nmom * lp->locV3;
+  const size_t cb = lp->cplxBytes();
+  if ((st = dev_alloc(lp, &lp->dataPos_d, (size_t)lp->nElemPosLoc * cb, true))) return fail(st);
+  if (lp->doMomProj) {
+    lp->dataMom_bcast = calloc((size_t)lp->nElemMomTot, cb);
+    lp->dataMom_h = calloc((size_t)lp->nElemMomLoc, cb);
+    lp->dataMom = calloc((size_t)lp->nElemMomLoc, cb);
+    if (!lp->dataMom_bcast || !lp->dataMom_h || !lp->dataMom) {
+      set_error(MUGIQ_HIP_ERROR_HIP, "%s: Could not allocate host buffers dataMom*", who);
+      return fail(MUGIQ_HIP_ERROR_HIP);
+    }
+    if ((st = dev_alloc(lp, &lp->phaseMatrix_d, (size_t)lp->nElemPhMat * cb, true))) return fail(st);
+    if ((st = dev_alloc(lp, &lp->dataMom_d, (size_t)lp->nElemMomLoc * cb, true))) return fail(st);
+    if ((st = dev_alloc(lp, &lp->dataPosMP_d, (size_t)lp->nElemPosLoc * cb, true))) return fail(st);
+  }
+  // copyGammaToConstMem :162-167, createPhaseMatrix :171-178
+  if ((st = mugiq_hip_copy_gamma_coeff_to_symbol(lp->precision))) return fail(st);
+  if (lp->doMomProj) {
+    if ((st = mugiq_hip_copy_gamma_map_to_symbol(lp->precision))) return fail(st);
+    int cc[4] = {0, 0, 0, 0};
+    if (lp->haveComm)
+      for (int d = 0; d < 4; d++) cc[d] = lp->comm.coord[d];
+    if ((st = mugiq_hip_create_phase_matrix(lp->phaseMatrix_d, lp->momMatrix.data(), lp->locV3, lp->Nmom, lp->FTSign, lp->localL,
+                                            lp->totalL, cc, lp->precision, lp->stream)))
+      return fail(st);
+  }
+  *out = lp;
+  return MUGIQ_HIP_SUCCESS;
+}
+
+int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
+  MUGIQ_REQUIRE(lp != nullptr, "computeCoarseLoop: NULL loop handle");
+  int st = MUGIQ_HIP_SUCCESS;
+  const size_t cb = lp->cplxBytes();
+  const bool basic = lp->calcType == MUGIQ_HIP_LOOP_CALC_TYPE_BASIC_KERNEL;
+  for (int id = -1; id < lp->nDispEntries; id++) {  // lib/loop_mugiq.cpp:455
+    long long bufOffset;
+    size_t bufByteSize;
+    if (id != -1) {  // :465-474
+      bufOffset = lp->nElemPosLocPerLoop * lp->nLoopOffset[id];
+      bufByteSize = cb * (size_t)lp->nElemPosLocPerLoop * lp->nLoopPerEntry[id];
+    } else {
+      bufOffset = 0;
+      bufByteSize = cb * (size_t)lp->nElemPosLocPerLoop;
+    }
+    void *slot0 = static_cast<char *>(lp->dataPos_d) + (size_t)bufOffset * cb;
+    MUGIQ_CHECK_HIP(hipMemsetAsync(slot0, 0, bufByteSize, lp->stream));  // :476
+    if (id == -1) {
+      if (basic) {
+        for (int n = 0; n < lp->nEv && !st; n++)  // :501-502
+          st = mugiq_hip_perform_loop_contraction(slot0, &lp->eVecs[n], &lp->eVecs[n], lp->sigma[n], lp->stream);
+      } else {
+        st = mugiq_hip_perform_loop_contraction_batched(slot0, lp->eVecs.data(), lp->eVecs.data(), lp->sigma.data(), lp->nEv,
+                                                        lp->stream);
+      }
+    } else {
+      st = basic ? entry_basic(lp, id, slot0) : entry_fused(lp, id, slot0);
+      hipError_t e = hipStreamSynchronize(lp->stream);
+      free_scratch(lp);
+      if (!st && e != hipSuccess) st = set_error(MUGIQ_HIP_ERROR_HIP, "computeCoarseLoop: %s", hipGetErrorString(e));
+    }
+    if (st) return st;
+  }
+  lp->dataPosCopied = false;
+  if (lp->doMomProj && (st = momentum_projection(lp))) return st;  // :517-520
+  MUGIQ_CHECK_HIP(hipStreamSynchronize(lp->stream));
+  lp->computed = true;
+  return MUGIQ_HIP_SUCCESS;
+}
+
+int mugiq_hip_loop_get_info(const MugiqHipLoop *lp, MugiqHipLoopInfo *info) {
+  MUGIQ_REQUIRE(lp && info, "mugiq_hip_loop_get_info: NULL argument");
+  info->nDispEntries = lp->nDispEntries;
+  info->nLoop = lp->nLoop;
+  info->nData = lp->nData;
+  info->Nmom = lp->Nmom;
+  info->precision = lp->precision;
+  info->field_order = lp->order;
+  for (int d = 0; d < 4; d++) {
+    info->localL[d] = lp->localL[d];
+    info->totalL[d] = lp->totalL[d];
+  }
+  info->locT = lp->locT;
+  info->totT = lp->totT;
+  info->locV4 = lp->locV4;
+  info->locV3 = lp->locV3;
+  info->totV3 = lp->totV3;
+  info->nElemPosLocPerLoop = lp->nElemPosLocPerLoop;
+  info->nElemMomLocPerLoop = lp->nElemMomLocPerLoop;
+  info->nElemMomTotPerLoop = lp->nElemMomTotPerLoop;
+  info->nElemPosLoc = lp->nElemPosLoc;
+  info->nElemMomLoc = lp->nElemMomLoc;
+  info->nElemMomTot = lp->nElemMomTot;
+  info->nElemPhMat = lp->nElemPhMat;
+  return MUGIQ_HIP_SUCCESS;
+}
+
+int mugiq_hip_loop_get_entry(const MugiqHipLoop *lp, int id, int out6[6]) {
+  MUGIQ_REQUIRE(lp && out6, "mugiq_hip_loop_get_entry: NULL argument");
+  MUGIQ_REQUIRE(id >= 0 && id < lp->nDispEntries, "mugiq_hip_loop_get_entry: entry %d out of range [0,%d)", id, lp->nDispEntries);
+  out6[0] = lp->dispDir[id];
+  out6[1] = lp->dispSign[id];
+  out6[2] = lp->dispStart[id];
+  out6[3] = lp->dispStop[id];
+  out6[4] = lp->nLoopPerEntry[id];
+  out6[5] = lp->nLoopOffset[id];
+  return MUGIQ_HIP_SUCCESS;
+}
+
+const void *mugiq_hip_loop_data_pos_d(const MugiqHipLoop *lp) { return lp ? lp->dataPos_d : nullptr; }
+
+const void *mugiq_hip_loop_data_pos_h(MugiqHipLoop *lp) {
+  if (!lp) return nullptr;
+  const size_t bytes = (size_t)lp->nElemPosLoc * lp->cplxBytes();
+  if (!lp->dataPos) lp->dataPos = calloc((size_t)lp->nElemPosLoc, lp->cplxBytes());  // lib/loop_mugiq.cpp:116
+  if (!lp->dataPos) return nullptr;
+  if (!lp->dataPosCopied) {
+    if (hipMemcpy(lp->dataPos, lp->dataPos_d, bytes, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;  // :512
+    lp->dataPosCopied = true;
+  }
+  return lp->dataPos;
+}
+
+const void *mugiq_hip_loop_data_mom_bcast_h(const MugiqHipLoop *lp) { return (lp && lp->momProjDone) ? lp->dataMom_bcast : nullptr; }
+
+int mugiq_hip_loop_destroy(MugiqHipLoop *lp) {  // freeDataMemory, lib/loop_mugiq.cpp:182-229
+  if (!lp) return MUGIQ_HIP_SUCCESS;
+  free_scratch(lp);
+  free(lp->dataMom_bcast);
+  free(lp->dataMom_h);
+  free(lp->dataMom);
+  free(lp->dataPos);
+  if (lp->dataPos_d) (void)hipFree(lp->dataPos_d);
+  if (lp->dataPosMP_d) (void)hipFree(lp->dataPosMP_d);
+  if (lp->dataMom_d) (void)hipFree(lp->dataMom_d);
+  if (lp->phaseMatrix_d) (void)hipFree(lp->phaseMatrix_d);
+  delete lp;
+  return MUGIQ_HIP_SUCCESS;
+}
+
+}  // extern "C"

@@ -117,3 +117,23 @@ def momentumProjection(dataMom_d, dataPosMP_d, phaseMatrix_d, locT, nData, locV3
     _lib.check(_lib.load().mugiq_hip_momentum_projection(
         dataMom_d.data_ptr(), dataPosMP_d.data_ptr(), phaseMatrix_d.data_ptr(), int(locT), int(nData), int(locV3),
         int(Nmom), _prec_of(dataPosMP_d), None, 0, _stream()))
+
+
+def packFaceLayers(faces_d, eVecs, dim, high, layers):
+    """[nVec][layers] ghost zones in one buffer (see mugiq_hip_pack_face_layers)."""
+    d = desc_array(eVecs)
+    assert faces_d.numel() >= len(eVecs) * layers * 24 * eVecs[0].face_cb(dim)
+    _lib.check(_lib.load().mugiq_hip_pack_face_layers(faces_d.data_ptr(), d, len(eVecs), int(dim), int(high), int(layers), _stream()))
+
+
+def displacedLoopContractionFused(loopData_d, eVecs, sigmas, pathLinkFields, kValues, dispDir, dispSign,
+                                  commDim=(0, 0, 0, 0), ghostLayers_d=None, layers=0):
+    """loop slot i += sum_n (1/sigma_n) v_n^dag G W_k v_n(x +- k mu), k = kValues[i] (see mugiq_hip.h)."""
+    n, nk = len(eVecs), len(kValues)
+    d = desc_array(eVecs)
+    sg = (ctypes.c_double * n)(*[float(s) for s in sigmas])
+    links = (ctypes.c_void_p * nk)(*[f.data.data_ptr() for f in pathLinkFields])
+    kv = (ctypes.c_int * nk)(*[int(k) for k in kValues])
+    _lib.check(_lib.load().mugiq_hip_displaced_loop_contraction_fused(
+        loopData_d.data_ptr(), d, sg, n, links, kv, nk, int(dispDir), int(dispSign), _lib.int4(commDim),
+        ghostLayers_d.data_ptr() if ghostLayers_d is not None else None, int(layers), _stream()))

@@ -1,0 +1,148 @@
+"""Worker functions for the multi-process tests (spawned with torch.multiprocessing; one process per rank).
+
+`cpu_worker`  : world_size-2 gloo run on CPU -- exercises mugiq_amd.comm.GridComm (topology, face exchange,
+                space-reduce / time-gather / broadcast) with the oracle doing the per-rank arithmetic.
+`gpu_worker`  : the C++ driver (HIP kernels) on each rank, gloo transport with device buffers staged through
+                the host, all ranks sharing cuda:0 of the one-GPU box.
+Both compare against the single-domain oracle computed from the same seeded global fields.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _global_problem(G, nev, seed):
+    from util import random_gauge_lex, random_spinor_lex, sigmas
+    rng = np.random.default_rng(seed)
+    ev_lex = [random_spinor_lex(rng, G) for _ in range(nev)]
+    U_lex = random_gauge_lex(rng, G)
+    return ev_lex, U_lex, sigmas(nev)
+
+
+def _single_domain_reference(orc, G, ev_lex, U_lex, sg, disp, moms, FTSign):
+    cprm = orc.LoopComputeParam(*disp) if disp else orc.LoopComputeParam(doNonLocal=False)
+    Uo = orc.extended_gauge_from_global(U_lex, (0, 0, 0, 0), (1, 1, 1, 1), (0, 0, 0, 0))
+    pos = orc.compute_loop_position_space([orc.lex_to_eo(v, G) for v in ev_lex], sg, cprm, Uo, G)
+    V = int(np.prod(G))
+    locV3 = G[0] * G[1] * G[2]
+    mp_ = orc.convert_idx_order_map_gamma(pos, cprm.nData, cprm.nLoop, 2, V // 2, G)
+    mom = orc.momentum_projection_local(mp_, orc.phase_matrix(moms, locV3, FTSign, G, G), G[3], cprm.nData, locV3, len(moms))
+    return cprm, pos, mom.reshape(len(moms), cprm.nLoop, 16, G[3])
+
+
+def _init(rank, world, port, backend="gloo"):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist
+
+
+def _check_pos(orc, rank_coord, grid, G, l, cprm, pos_local, pos_global, tol):
+    from util import rel_err
+    Vg, Vl = int(np.prod(G)), int(np.prod(l))
+    for idata in range(cprm.nData):
+        glob = orc.eo_to_lex(pos_global[Vg * idata:Vg * (idata + 1)].reshape(2, Vg // 2), G)
+        loc = orc.eo_to_lex(pos_local[Vl * idata:Vl * (idata + 1)].reshape(2, Vl // 2), l)
+        e = rel_err(loc, orc.local_block(glob, rank_coord, grid))
+        assert e < tol, ("dataPos", idata, e)
+
+
+def cpu_worker(rank, world, port, grid):
+    """N>1 path on CPU: GridComm over gloo + oracle arithmetic == single-domain oracle."""
+    import torch
+    from util import orc, momenta_p2_le, rel_err
+    dist = _init(rank, world, port)
+    from mugiq_amd.comm import GridComm
+    G = (4, 4, 4, 8)
+    disp = (["+t", "-t", "+z", "-x"], [1, 1, 2, 1], [2, 1, 2, 1])
+    moms = momenta_p2_le(2)
+    FTSign = -1
+    ev_lex, U_lex, sg = _global_problem(G, 2, 99)
+    cprm, pos_g, mom_g = _single_domain_reference(orc, G, ev_lex, U_lex, sg, disp, moms, FTSign)
+
+    comm = GridComm(grid)
+    assert comm.rank_of(comm.coord) == rank and comm.coords_of(rank) == comm.coord
+    l = [G[d] // grid[d] for d in range(4)]
+    commDim = [comm.comm_dim_partitioned(d) for d in range(4)]
+    brd = [2 * c for c in commDim]
+    U = orc.extended_gauge_from_global(U_lex, comm.coord, grid, brd)
+    ev = [orc.lex_to_eo(orc.local_block(v, comm.coord, grid), l) for v in ev_lex]
+
+    def ghost_exchange(v):
+        """exchangeGhostVec: all partitioned dims, both directions, through GridComm.sendrecv"""
+        gh = [[None, None] for _ in range(4)]
+        for d in range(4):
+            if not commDim[d]:
+                continue
+            for high in (0, 1):
+                face = torch.from_numpy(np.ascontiguousarray(orc.pack_face(v, l, d, high)))
+                recv = torch.empty_like(face)
+                comm.sendrecv(face, recv, d, +1 if high else -1)       # low face -> backward nbr; high -> forward
+                gh[d][1 - high] = recv.numpy()
+        return gh
+
+    pos = orc.compute_loop_position_space(ev, sg, cprm, U, l, commDim, brd, ghost_exchange)
+    _check_pos(orc, comm.coord, grid, G, l, cprm, pos, pos_g, 1e-13)
+
+    # momentum projection with the COMM_SPACE reduce / COMM_TIME gather / world bcast
+    Vl = int(np.prod(l))
+    locV3 = l[0] * l[1] * l[2]
+    ph = orc.phase_matrix(moms, locV3, FTSign, l, G, comm.coord)
+    mom_loc = orc.momentum_projection_local(orc.convert_idx_order_map_gamma(pos, cprm.nData, cprm.nLoop, 2, Vl // 2, l),
+                                            ph, l[3], cprm.nData, locV3, len(moms))
+    send = torch.from_numpy(mom_loc.view(np.float64).copy())
+    red = torch.zeros_like(send)
+    comm.reduce_space(send, red)
+    full = torch.zeros(send.numel() * grid[3], dtype=send.dtype)
+    comm.gather_time(red, full)
+    comm.bcast(full)
+    got = full.numpy().view(np.complex128).reshape(grid[3], len(moms), cprm.nLoop, 16, l[3])
+    got = got.transpose(1, 2, 3, 0, 4).reshape(len(moms), cprm.nLoop, 16, G[3])
+    assert rel_err(got, mom_g) < 1e-12
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gpu_worker(rank, world, port, grid, prec, order, calc_type):
+    """The C++ driver on every rank (all on cuda:0), halos and FT reduction through the comm callbacks."""
+    import torch
+    from util import orc, momenta_p2_le, rel_err
+    dist = _init(rank, world, port)
+    torch.cuda.set_device(0)
+    import mugiq_amd as hip
+    G = (4, 4, 8, 8)
+    disp = (["+t", "-t", "+z", "-z", "+x", "-y"], [1, 2, 1, 1, 1, 2], [3, 2, 2, 1, 1, 2])
+    moms = momenta_p2_le(2)
+    FTSign = 1
+    nev = 3
+    ev_lex, U_lex, sg = _global_problem(G, nev, 1234)
+    cdt = np.complex128 if prec == 8 else np.complex64
+    ev_lex = [v.astype(cdt).astype(np.complex128) for v in ev_lex]           # the inputs the GPU sees
+    U_lex = U_lex.astype(cdt).astype(np.complex128)
+    cprm, pos_g, mom_g = _single_domain_reference(orc, G, ev_lex, U_lex, sg, disp, moms, FTSign)
+
+    comm = hip.GridComm(grid, device="cuda:0")
+    l = [G[d] // grid[d] for d in range(4)]
+    brd = [2 * comm.comm_dim_partitioned(d) for d in range(4)]
+    gauge = hip.GaugeField(l, brd, prec).set_logical(orc.extended_gauge_from_global(U_lex, comm.coord, grid, brd))
+    f = [hip.SpinorField(l, prec, order).set_logical(orc.lex_to_eo(orc.local_block(v, comm.coord, grid), l)) for v in ev_lex]
+    prm = hip.MugiqLoopParam(Nmom=len(moms), momMatrix=[list(m) for m in moms], FTSign=FTSign, calcType=calc_type,
+                             doMomProj=True, doNonLocal=True, disp_entry=[], disp_str=disp[0], disp_start=disp[1],
+                             disp_stop=disp[2], gauge=gauge)
+    loop = hip.Loop_Mugiq(prm, f, sg, comm)
+    assert loop.nLoop == cprm.nLoop and loop.totT == G[3] and loop.locT == l[3]
+    loop.computeCoarseLoop()
+    tol = 1e-12 if prec == 8 else 1e-5
+    _check_pos(orc, comm.coord, grid, G, l, cprm, loop.dataPos_d.cpu().numpy().astype(np.complex128), pos_g, tol)
+    e = rel_err(loop.dataMom_global(), mom_g)
+    assert e < tol, ("dataMom", e)
+    loop.close()
+    dist.barrier()
+    dist.destroy_process_group()

@@ -1,0 +1,137 @@
+"""GPU tests of the C++ driver (Loop_Mugiq / Displace mirror): slot bookkeeping, both execution plans
+(BASIC = the reference's launch sequence, OPT = batched + fused), momentum projection, and the
+domain-decomposed run (2 ranks sharing the one GPU of the box, gloo transport through the comm callbacks)."""
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import mp_workers
+from test_multi_rank_cpu import free_port
+from util import orc, random_gauge_lex, random_spinor_lex, sigmas, momenta_p2_le, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(hip, X, nev, prec, order, seed):
+    rng = np.random.default_rng(seed)
+    cdt = np.complex128 if prec == 8 else np.complex64
+    ev = [orc.lex_to_eo(random_spinor_lex(rng, X), X).astype(cdt).astype(np.complex128) for _ in range(nev)]
+    Uo = orc.extended_gauge_from_global(random_gauge_lex(rng, X), (0, 0, 0, 0), (1, 1, 1, 1), (0, 0, 0, 0))
+    Uo = Uo.astype(cdt).astype(np.complex128)
+    f = [hip.SpinorField(X, prec, order).set_logical(v) for v in ev]
+    U = hip.GaugeField(X, (0, 0, 0, 0), prec).set_logical(Uo)
+    return ev, Uo, f, U
+
+
+@pytest.mark.parametrize("prec,order", [(8, 2), (8, 4), (4, 2), (4, 4)])
+@pytest.mark.parametrize("calc", ["basic", "opt"])
+def test_driver_single_process_vs_oracle(hip, prec, order, calc):
+    X = (4, 6, 4, 8)
+    nev = 5
+    ev, Uo, f, U = _setup(hip, X, nev, prec, order, 321)
+    sg = sigmas(nev)
+    entry = "+z:1,2;-x:2;+t:3,1;-y:1;-t:1,5"               # includes start > stop (swapped) and 5 slots (> 4 per launch)
+    prm = hip.MugiqLoopParam(FTSign=-1, doMomProj=True, gauge=U,
+                             calcType=hip.LOOP_CALC_TYPE_BASIC_KERNEL if calc == "basic" else hip.LOOP_CALC_TYPE_OPT_KERNEL)
+    prm.set_displace_entry_string(entry)
+    moms = momenta_p2_le(3)
+    prm.momMatrix, prm.Nmom = [list(m) for m in moms], len(moms)
+    loop = hip.Loop_Mugiq(prm, f, sg)
+    _, s, a, b = orc.parse_disp_entry_string(entry)
+    cprm = orc.LoopComputeParam(s, a, b)
+    assert (loop.nLoop, loop.nData, loop.nDispEntries) == (cprm.nLoop, cprm.nData, cprm.nDispEntries)
+    for i in range(cprm.nDispEntries):
+        d, sgn = orc.parse_displacement(cprm.dispString[i])
+        assert loop.entry(i) == (d, sgn, cprm.dispStart[i], cprm.dispStop[i], cprm.nLoopPerEntry[i], cprm.nLoopOffset[i])
+    V = int(np.prod(X))
+    assert loop.nElemPosLoc == 16 * V * cprm.nLoop and loop.nElemMomTot == 16 * len(moms) * X[3] * cprm.nLoop
+    loop.computeCoarseLoop()
+    ref_pos = orc.compute_loop_position_space(ev, sg, cprm, Uo, X)
+    tol = 1e-12 if prec == 8 else 1e-5
+    assert rel_err(loop.dataPos_d.cpu().numpy(), ref_pos) < tol
+    locV3 = X[0] * X[1] * X[2]
+    ref_mom = orc.momentum_projection_local(orc.convert_idx_order_map_gamma(ref_pos, cprm.nData, cprm.nLoop, 2, V // 2, X),
+                                            orc.phase_matrix(moms, locV3, -1, X, X), X[3], cprm.nData, locV3, len(moms))
+    assert rel_err(loop.dataMom_bcast, ref_mom) < tol
+    loop.close()
+
+
+def test_driver_ultralocal_only_and_errors(hip):
+    X = (4, 4, 4, 4)
+    ev, Uo, f, U = _setup(hip, X, 3, 8, 2, 5)
+    sg = sigmas(3)
+    loop = hip.Loop_Mugiq(hip.MugiqLoopParam(), f, sg)          # no mom-proj, no displacements
+    assert loop.nLoop == 1 and loop.dataMom_bcast is None
+    loop.computeCoarseLoop()
+    ref = orc.compute_loop_position_space(ev, sg, orc.LoopComputeParam(doNonLocal=False))
+    assert rel_err(loop.dataPos_d.cpu().numpy(), ref) < 1e-13
+    loop.close()
+    with pytest.raises(hip.MugiqHipError):                       # displacements without a gauge field
+        hip.Loop_Mugiq(hip.MugiqLoopParam().set_displace_entry_string("+x:1"), f, sg)
+    with pytest.raises(hip.MugiqHipError):                       # unparsable displacement string
+        hip.Loop_Mugiq(hip.MugiqLoopParam(doNonLocal=True, disp_str=["+w"], disp_start=[1], disp_stop=[1], gauge=U), f, sg)
+    with pytest.raises(hip.MugiqHipError):                       # mismatched limits
+        hip.Loop_Mugiq(hip.MugiqLoopParam(doNonLocal=True, disp_str=["+x"], disp_start=[1, 2], disp_stop=[1], gauge=U), f, sg)
+    with pytest.raises(hip.MugiqHipError):                       # momentum projection without momenta
+        hip.Loop_Mugiq(hip.MugiqLoopParam(doMomProj=True), f, sg)
+
+
+@pytest.mark.parametrize("order", [2, 4])
+def test_fused_operator_with_ghost_layers(hip, order):
+    """Operator-level check of the fused kernel across a domain boundary (2 domains emulated on one GPU):
+    path links from E_k = D^k E_0 per domain, 3 ghost layers packed by pack_face_layers."""
+    G = (4, 4, 4, 8)
+    grid = (1, 1, 1, 2)
+    l = (4, 4, 4, 4)
+    comm = (0, 0, 0, 1)
+    brd = (0, 0, 0, 2)
+    rng = np.random.default_rng(8)
+    nev = 3
+    ev_lex = [random_spinor_lex(rng, G) for _ in range(nev)]
+    U_lex = random_gauge_lex(rng, G)
+    sg = sigmas(nev)
+    ranks = [(0, 0, 0, 0), (0, 0, 0, 1)]
+    for dispstr in ("+t", "-t"):
+        dirn, sign = orc.parse_displacement(dispstr)
+        cprm = orc.LoopComputeParam([dispstr], [1], [3])
+        ref = orc.compute_loop_position_space([orc.lex_to_eo(v, G) for v in ev_lex], sg, cprm,
+                                              orc.extended_gauge_from_global(U_lex, (0, 0, 0, 0), (1, 1, 1, 1), (0, 0, 0, 0)), G)
+        f = {r: [hip.SpinorField(l, 8, order).set_logical(orc.lex_to_eo(orc.local_block(v, r, grid), l)) for v in ev_lex] for r in ranks}
+        Ue = {r: hip.GaugeField(l, brd, 8).set_logical(orc.extended_gauge_from_global(U_lex, r, grid, brd)) for r in ranks}
+        high = 0 if sign == hip.DispSignPlus else 1
+        # path links per rank (needs the depth-1 face of E_{k-1} from the neighbour at every step)
+        E = {r: [hip.SpinorField(l, 8, 2) for _ in range(4)] for r in ranks}
+        ident = np.zeros((2, 128, 4, 3), dtype=np.complex128)
+        for s in range(3):
+            ident[:, :, s, s] = 1.0
+        for r in ranks:
+            E[r][0].set_logical(ident)
+        for k in range(1, 4):
+            faces = {}
+            for r in ranks:
+                faces[r] = torch.zeros(24 * E[r][k - 1].face_cb(3), dtype=torch.complex128, device="cuda")
+                hip.packFace(faces[r], E[r][k - 1], 3, high)
+            for i, r in enumerate(ranks):
+                E[r][k - 1].ghost[3][1 - high] = faces[ranks[1 - i]]
+                hip.performCovariantDisplacementVector(E[r][k], E[r][k - 1], Ue[r], dirn, sign, comm)
+        layers = {}
+        for r in ranks:
+            layers[r] = torch.zeros(nev * 3 * 24 * f[r][0].face_cb(3), dtype=torch.complex128, device="cuda")
+            hip.packFaceLayers(layers[r], f[r], 3, high, 3)
+        Vl, Vg = 256, 512
+        for i, r in enumerate(ranks):
+            out = torch.zeros(3 * 16 * Vl, dtype=torch.complex128, device="cuda")
+            hip.displacedLoopContractionFused(out, f[r], sg, E[r][1:], [1, 2, 3], dirn, sign, comm, layers[ranks[1 - i]], 3)
+            got = out.cpu().numpy()
+            for k in range(3):
+                for ig in range(16):
+                    gl = orc.eo_to_lex(ref[Vg * (16 * (1 + k) + ig):Vg * (16 * (1 + k) + ig + 1)].reshape(2, Vg // 2), G)
+                    lo = orc.eo_to_lex(got[Vl * (16 * k + ig):Vl * (16 * k + ig + 1)].reshape(2, Vl // 2), l)
+                    assert rel_err(lo, orc.local_block(gl, r, grid)) < 1e-13, (dispstr, r, k, ig)
+
+
+@pytest.mark.parametrize("grid,prec,order,calc", [((1, 1, 1, 2), 8, 2, 1), ((1, 1, 2, 1), 8, 4, 1), ((1, 1, 1, 2), 8, 2, 2),
+                                                  ((1, 1, 2, 1), 4, 4, 2), ((2, 1, 1, 1), 4, 2, 1)])
+def test_two_rank_driver_on_one_gpu(grid, prec, order, calc):
+    mp.spawn(mp_workers.gpu_worker, args=(2, free_port(), grid, prec, order, calc), nprocs=2, join=True)

@@ -1,0 +1,26 @@
+"""world_size-2 `gloo` tests of the N>1 path on CPU: the comm layer the driver's callbacks use (process grid,
+nearest-neighbour face exchange, COMM_SPACE reduce, COMM_TIME gather, broadcast) with the oracle doing the
+per-rank arithmetic, checked against the single-domain oracle."""
+import socket
+
+import pytest
+import torch.multiprocessing as mp
+
+import mp_workers
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("grid", [(1, 1, 1, 2), (1, 1, 2, 1), (2, 1, 1, 1)])
+def test_two_rank_gloo_loop_equals_single_domain(grid):
+    mp.spawn(mp_workers.cpu_worker, args=(2, free_port(), grid), nprocs=2, join=True)
+
+
+def test_four_rank_gloo_z_and_t_partitioned():
+    mp.spawn(mp_workers.cpu_worker, args=(4, free_port(), (1, 1, 2, 2)), nprocs=4, join=True)
