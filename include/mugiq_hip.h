@@ -283,6 +283,16 @@ const void *mugiq_hip_loop_data_pos_h(MugiqHipLoop *loop);
 /* dataMom_bcast (host): per time-rank slabs of t + locT*ig + locT*16*iL + locT*16*nLoop*im, concatenated in
  * coord[3] order (lib/loop_mugiq.cpp:415-424).  NULL before compute or without doMomProj. */
 const void *mugiq_hip_loop_data_mom_bcast_h(const MugiqHipLoop *loop);
+/* Loop_Mugiq::writeLoopsHDF5()  lib/loop_mugiq.cpp:668-693 -> writeLoopsHDF5_Mom :529-656: group tree
+ * /mom_%+d_%+d_%+d/disp_0|disp_<+-dir>_<len>/<GammaName>/loop, dataset [totT][2] of native float|double.
+ * World rank 0 writes the whole file with serial HDF5 from dataMom_bcast (libhdf5 is bound at run time; override the
+ * library with MUGIQ_HIP_HDF5_LIB).  Position-space output is "Not supported yet!" as in the reference (:660-663). */
+int mugiq_hip_loop_write_hdf5(MugiqHipLoop *loop);
+/* The writer on its own (host only, no GPU needed): dataMom_bcast_h as laid out by performMomentumProjection
+ * (lib/loop_mugiq.cpp:415-424); disp_start <= disp_stop already normalised; nLoop = 1 + sum(stop-start+1). */
+int mugiq_hip_write_loops_hdf5_mom(const char *filename, const void *dataMom_bcast_h, int precision, int Nmom,
+                                   const int *momMatrix, int nDispEntries, const char *const *disp_str,
+                                   const int *disp_start, const int *disp_stop, int locT, int totT);
 /* Loop_Mugiq::~Loop_Mugiq */
 int mugiq_hip_loop_destroy(MugiqHipLoop *loop);
 

@@ -78,6 +78,9 @@ SIGNATURES = {
     "mugiq_hip_loop_data_pos_d": (_VP, [_VP]),
     "mugiq_hip_loop_data_pos_h": (_VP, [_VP]),
     "mugiq_hip_loop_data_mom_bcast_h": (_VP, [_VP]),
+    "mugiq_hip_loop_write_hdf5": (ctypes.c_int, [_VP]),
+    "mugiq_hip_write_loops_hdf5_mom": (ctypes.c_int, [ctypes.c_char_p, _VP, ctypes.c_int, ctypes.c_int, _I4, ctypes.c_int,
+                                                      ctypes.POINTER(ctypes.c_char_p), _I4, _I4, ctypes.c_int, ctypes.c_int]),
     "mugiq_hip_loop_destroy": (ctypes.c_int, [_VP]),
     "mugiq_hip_parse_displace_entry_string": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, _I4, _I4]),
     "mugiq_hip_parse_displacement": (ctypes.c_int, [ctypes.c_char_p, _I4, _I4]),

@@ -9,6 +9,7 @@
 // of swapAuxDispVec (lib/displace.cpp:47-59), the per-launch cudaMalloc/cudaMemcpy/cudaFree/cudaDeviceSynchronize
 // (lib/contract_wrappers.cu:93-114), and the exchange of all four faces in both directions per step.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -73,6 +74,10 @@ struct MugiqHipLoop_s {
 };
 
 namespace mugiq {
+
+int write_loops_hdf5_mom(const char *filename, const void *dataMom_bcast, int precision, int Nmom, const int *momMatrix,
+                         int nDispEntries, const std::vector<std::string> &dispString, const std::vector<int> &dispStart,
+                         const std::vector<int> &dispStop, int nLoop, int locT, int totT);  // hdf5_writer.cpp
 
 static int dev_alloc(MugiqHipLoop *lp, void **p, size_t bytes, bool zero) {
   MUGIQ_CHECK_HIP(hipMalloc(p, bytes ? bytes : 16));
@@ -554,6 +559,53 @@ const void *mugiq_hip_loop_data_pos_h(MugiqHipLoop *lp) {
 }
 
 const void *mugiq_hip_loop_data_mom_bcast_h(const MugiqHipLoop *lp) { return (lp && lp->momProjDone) ? lp->dataMom_bcast : nullptr; }
+
+int mugiq_hip_write_loops_hdf5_mom(const char *filename, const void *dataMom_bcast_h, int precision, int Nmom,
+                                   const int *momMatrix, int nDispEntries, const char *const *disp_str, const int *disp_start,
+                                   const int *disp_stop, int locT, int totT) {
+  const char *who = "writeLoopsHDF5_Mom";
+  MUGIQ_REQUIRE(filename && filename[0] && dataMom_bcast_h && momMatrix, "%s: NULL / empty argument", who);
+  MUGIQ_REQUIRE(precision == 4 || precision == 8, "%s: Precision not supported!", who);
+  MUGIQ_REQUIRE(Nmom >= 1 && locT >= 1 && totT >= locT && totT % locT == 0, "%s: invalid sizes Nmom=%d locT=%d totT=%d", who, Nmom, locT, totT);
+  MUGIQ_REQUIRE(nDispEntries >= 0 && (nDispEntries == 0 || (disp_str && disp_start && disp_stop)), "%s: invalid displacement entries", who);
+  std::vector<std::string> ds;
+  std::vector<int> a, b;
+  int nLoop = 1;
+  for (int i = 0; i < nDispEntries; i++) {
+    MUGIQ_REQUIRE(disp_str[i] && disp_start[i] >= 1 && disp_start[i] <= disp_stop[i], "%s: invalid displacement entry %d", who, i);
+    ds.push_back(disp_str[i]);
+    a.push_back(disp_start[i]);
+    b.push_back(disp_stop[i]);
+    nLoop += disp_stop[i] - disp_start[i] + 1;
+  }
+  return write_loops_hdf5_mom(filename, dataMom_bcast_h, precision, Nmom, momMatrix, nDispEntries, ds, a, b, nLoop, locT, totT);
+}
+
+// Loop_Mugiq::writeLoopsHDF5  lib/loop_mugiq.cpp:668-693
+int mugiq_hip_loop_write_hdf5(MugiqHipLoop *lp) {
+  MUGIQ_REQUIRE(lp != nullptr, "writeLoopsHDF5: NULL loop handle");
+  MUGIQ_REQUIRE(lp->computed, "writeLoopsHDF5: computeCoarseLoop has not been called");
+  if (lp->doMomProj) {
+    if (!lp->writeMom) {
+      fprintf(stderr, "writeLoopsHDF5: Performed momentum projection, but got writeDatMom = FALSE.\n"
+                      "writeLoopsHDF5: Will proceed to write momentum-space loop data\n");
+      lp->writeMom = true;
+    }
+    MUGIQ_REQUIRE(!lp->fnameMom.empty(), "Got --loop-write-mom-space yes but no filename was given. Set option --loop-mom-space-filename");
+    if (!lp->haveComm || lp->comm.rank == 0) {  // dataMom_bcast is replicated; one writer produces the identical file
+      int st = write_loops_hdf5_mom(lp->fnameMom.c_str(), lp->dataMom_bcast, lp->precision, lp->Nmom, lp->momMatrix.data(),
+                                    lp->nDispEntries, lp->dispString, lp->dispStart, lp->dispStop, lp->nLoop, lp->locT, lp->totT);
+      if (st) return st;
+    }
+  } else if (!lp->writePos) {
+    fprintf(stderr, "writeLoopsHDF5: Did not perform momentum projection, but got writeDatPos = FALSE.\n"
+                    "writeLoopsHDF5: Will proceed to write position-space loop data\n");
+    lp->writePos = true;
+  }
+  if (lp->writePos)  // Loop_Mugiq::writeLoopsHDF5_Pos is an errorQuda in the reference too (:660-663)
+    return set_error(MUGIQ_HIP_ERROR_UNSUPPORTED, "writeLoopsHDF5_Pos: Not supported yet!");
+  return MUGIQ_HIP_SUCCESS;
+}
 
 int mugiq_hip_loop_destroy(MugiqHipLoop *lp) {  // freeDataMemory, lib/loop_mugiq.cpp:182-229
   if (!lp) return MUGIQ_HIP_SUCCESS;

@@ -91,6 +91,20 @@ def read_momenta_file(path):
     return out
 
 
+def writeLoopsHDF5_Mom(filename, dataMom_bcast, momMatrix, disp_str, disp_start, disp_stop, locT, totT):
+    """Stand-alone momentum-space writer (host only): the file tree of lib/loop_mugiq.cpp:529-656."""
+    a = np.ascontiguousarray(dataMom_bcast)
+    prec = 8 if a.dtype == np.complex128 else 4
+    mom = np.ascontiguousarray(np.asarray(momMatrix, dtype=np.int32).reshape(-1))
+    ne = len(disp_str)
+    ds = (ctypes.c_char_p * max(ne, 1))(*[s.encode() for s in disp_str])
+    st = (ctypes.c_int * max(ne, 1))(*[int(x) for x in disp_start])
+    sp = (ctypes.c_int * max(ne, 1))(*[int(x) for x in disp_stop])
+    _lib.check(_lib.load().mugiq_hip_write_loops_hdf5_mom(
+        filename.encode(), a.ctypes.data_as(ctypes.c_void_p), prec, mom.size // 3, mom.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+        ne, ds, st, sp, int(locT), int(totT)))
+
+
 class Loop_Mugiq:
     """Loop_Mugiq<Float, order>(loopParams, eigsolve): Float/order come from the eigenvector fields;
     `eVecs` / `eVals_sigma` are what the reference reads out of Eigsolve_Mugiq (lib/loop_mugiq.cpp:442,479)."""
@@ -176,6 +190,10 @@ class Loop_Mugiq:
         b = self.dataMom_bcast
         nt = self.totT // self.locT
         return b.reshape(nt, self.Nmom, self.nLoop, 16, self.locT).transpose(1, 2, 3, 0, 4).reshape(self.Nmom, self.nLoop, 16, self.totT)
+
+    def writeLoopsHDF5(self):
+        """lib/loop_mugiq.cpp:668-693 (momentum-space file; rank 0 writes)"""
+        _lib.check(_lib.load().mugiq_hip_loop_write_hdf5(self._handle))
 
     def close(self):
         if self._handle:
