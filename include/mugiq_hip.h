@@ -296,6 +296,16 @@ int mugiq_hip_write_loops_hdf5_mom(const char *filename, const void *dataMom_bca
 /* Loop_Mugiq::~Loop_Mugiq */
 int mugiq_hip_loop_destroy(MugiqHipLoop *loop);
 
+/* ---- a6 (setup): Displace::createExtendedCudaGaugeField  lib/displace.cpp:70-134 ------------------------------------ */
+/* bytes of a pad-0 extended field: volExCB * 36 * 2 parities * sizeof(complex) */
+size_t mugiq_hip_extended_gauge_bytes(const int X[4], const int R[4], int precision);
+/* Fill gauge->data (device, caller-allocated, descriptor complete) from the host links of the LOCAL lattice in
+ * QDP order, qdpLinks_h[dir][(parity*V/2 + x_cb)*18 + (row*3+col)*2 + re/im] of cpuPrecision (4|8)
+ * (loopParams.gauge[4], tests/loop.cpp:88,106,902-918), then fill the R-deep borders: neighbour slabs through
+ * comm->sendrecv for partitioned dims (edges/corners included, like exchangeExtendedGhost), periodic wrap otherwise. */
+int mugiq_hip_create_extended_gauge(const MugiqHipGaugeField *gauge, const void *const qdpLinks_h[4], int cpuPrecision,
+                                    const MugiqHipComm *comm, void *stream);
+
 /* ---- user syntax (tests/loop.cpp:607-705) -------------------------------------------------------------------------- */
 /* Parse "+z:1,8;-x:3;+y:2,5".  Returns the number of entries (<= max_entries) or a negative MugiqHipStatus.
  * disp_str_out: max_entries x 4 chars ("+z\0"); start/stop as in setLoopParam. */

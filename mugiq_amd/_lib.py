@@ -82,6 +82,8 @@ SIGNATURES = {
     "mugiq_hip_write_loops_hdf5_mom": (ctypes.c_int, [ctypes.c_char_p, _VP, ctypes.c_int, ctypes.c_int, _I4, ctypes.c_int,
                                                       ctypes.POINTER(ctypes.c_char_p), _I4, _I4, ctypes.c_int, ctypes.c_int]),
     "mugiq_hip_loop_destroy": (ctypes.c_int, [_VP]),
+    "mugiq_hip_extended_gauge_bytes": (ctypes.c_size_t, [_I4, _I4, ctypes.c_int]),
+    "mugiq_hip_create_extended_gauge": (ctypes.c_int, [_GP, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _VP, _VP]),
     "mugiq_hip_parse_displace_entry_string": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, _I4, _I4]),
     "mugiq_hip_parse_displacement": (ctypes.c_int, [ctypes.c_char_p, _I4, _I4]),
 }

@@ -136,6 +136,30 @@ class GaugeField:
         d.parity_offset = self.parity_offset
         return d
 
+    def set_from_qdp_host(self, qdp_links, comm=None):
+        """Displace::createExtendedCudaGaugeField (lib/displace.cpp:70-134): `qdp_links` = 4 host arrays of the LOCAL
+        lattice in QDP order (loopParams.gauge[4]); borders come from the neighbours through `comm` (a GridComm)."""
+        import ctypes
+        import torch
+        arrs = [np.ascontiguousarray(a) for a in qdp_links]
+        cpu_prec = 8 if arrs[0].dtype == np.float64 else 4
+        ptrs = (ctypes.c_void_p * 4)(*[a.ctypes.data for a in arrs])
+        d = self.desc()
+        c = comm.c_struct() if comm is not None else None
+        _lib.check(_lib.load().mugiq_hip_create_extended_gauge(
+            ctypes.byref(d), ptrs, cpu_prec, ctypes.byref(c) if c is not None else None,
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return self
+
+    def get_logical(self):
+        d = np.arange(4).reshape(4, 1, 1, 1, 1)
+        p = np.arange(2).reshape(1, 2, 1, 1, 1)
+        x = np.arange(self.volumeExCB).reshape(1, 1, -1, 1, 1)
+        r = np.arange(3).reshape(1, 1, 1, 3, 1)
+        c = np.arange(3).reshape(1, 1, 1, 1, 3)
+        idx = p * self.parity_offset + (d * 9 + r * 3 + c) * self.stride + x
+        return self.data.cpu().numpy()[idx]
+
     def set_logical(self, U):
         """U: [4, 2, volExCB, 3, 3] (dir, parity, extended even-odd index, row, col)."""
         U = np.asarray(U)

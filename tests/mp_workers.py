@@ -131,7 +131,11 @@ def gpu_worker(rank, world, port, grid, prec, order, calc_type):
     comm = hip.GridComm(grid, device="cuda:0")
     l = [G[d] // grid[d] for d in range(4)]
     brd = [2 * comm.comm_dim_partitioned(d) for d in range(4)]
-    gauge = hip.GaugeField(l, brd, prec).set_logical(orc.extended_gauge_from_global(U_lex, comm.coord, grid, brd))
+    # Displace's setup: host QDP links of the LOCAL lattice -> extended device field, borders from the neighbours
+    U_loc = np.stack([orc.lex_to_eo(orc.local_block(U_lex[mu], comm.coord, grid), l) for mu in range(4)])
+    gauge = hip.GaugeField(l, brd, prec).set_from_qdp_host(orc.gauge_to_qdp_host(U_loc), comm)
+    exp_ext = orc.extended_gauge_from_global(U_lex, comm.coord, grid, brd).astype(cdt)
+    assert np.array_equal(gauge.get_logical(), exp_ext), "extended gauge (borders, edges, corners) differs from the global field"
     f = [hip.SpinorField(l, prec, order).set_logical(orc.lex_to_eo(orc.local_block(v, comm.coord, grid), l)) for v in ev_lex]
     prm = hip.MugiqLoopParam(Nmom=len(moms), momMatrix=[list(m) for m in moms], FTSign=FTSign, calcType=calc_type,
                              doMomProj=True, doNonLocal=True, disp_entry=[], disp_str=disp[0], disp_start=disp[1],

@@ -171,3 +171,17 @@ def test_driver_writes_reference_hdf5_tree(hip, tmp_path):
     with pytest.raises(hip.MugiqHipError):
         l2.writeLoopsHDF5()
     l2.close()
+
+
+@pytest.mark.parametrize("prec", [8, 4])
+def test_extended_gauge_from_qdp_host_single_process(hip, prec):
+    """lib/displace.cpp:70-134 on one process: unpartitioned dims wrap periodically, any even total border."""
+    X = (4, 6, 4, 2)
+    rng = np.random.default_rng(2)
+    U_lex = random_gauge_lex(rng, X)
+    U_loc = np.stack([orc.lex_to_eo(U_lex[mu], X) for mu in range(4)])
+    cdt = np.complex128 if prec == 8 else np.complex64
+    for R in [(0, 0, 0, 0), (2, 0, 0, 2), (1, 1, 0, 0), (2, 2, 2, 2)]:
+        g = hip.GaugeField(X, R, prec).set_from_qdp_host(orc.gauge_to_qdp_host(U_loc))
+        exp = orc.extended_gauge_from_global(U_lex, (0, 0, 0, 0), (1, 1, 1, 1), R).astype(cdt)
+        assert np.array_equal(g.get_logical(), exp), R
