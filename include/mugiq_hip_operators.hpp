@@ -1,0 +1,246 @@
+// mugiq_hip_operators.hpp -- C++ host-side mirror of MuGiq's operator API over the C ABI of libmugiq_hip.so.
+//
+// Same template names, argument order and meaning as the reference's wrappers
+// (lib/contract_wrappers.cu; declared at include/loop_mugiq.h:280-311 and include/displace.h:109-111), with
+// MugiqHipSpinorField / MugiqHipGaugeField standing in for quda::ColorSpinorField / cudaGaugeField, plus the
+// enums (include/enum_mugiq.h), MugiqLoopParam (include/mugiq.h:28-47) and the public surface of
+// Loop_Mugiq<Float,order> (include/loop_mugiq.h:123-134).  Where the reference aborts through errorQuda, these
+// throw mugiq_hip::Error carrying the same message.  Header-only; link with -lmugiq_hip.
+//
+// Inside a MuGiq/QUDA build define MUGIQ_HIP_NO_REFERENCE_ENUMS (MuGiq's own enum_mugiq.h provides the enums)
+// and use the adapter of INTEGRATION.md to produce the descriptors from QUDA fields.
+#ifndef MUGIQ_HIP_OPERATORS_HPP
+#define MUGIQ_HIP_OPERATORS_HPP
+
+#include <climits>
+#include <complex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mugiq_hip.h"
+
+#ifndef MUGIQ_HIP_NO_REFERENCE_ENUMS
+#define MUGIQ_INVALID_ENUM INT_MIN
+// include/enum_mugiq.h:28-97 (values identical)
+typedef enum LoopFTSign_s { LOOP_FT_SIGN_MINUS = -1, LOOP_FT_SIGN_PLUS = 1, LOOP_FT_SIGN_INVALID = MUGIQ_INVALID_ENUM } LoopFTSign;
+typedef enum LoopCalcType_s {
+  LOOP_CALC_TYPE_BLAS,
+  LOOP_CALC_TYPE_OPT_KERNEL,
+  LOOP_CALC_TYPE_BASIC_KERNEL,
+  LOOP_CALC_TYPE_INVALID = MUGIQ_INVALID_ENUM
+} LoopCalcType;
+typedef enum DisplaceType_s { DISPLACE_TYPE_COVARIANT = 0, DISPLACE_TYPE_INVALID = MUGIQ_INVALID_ENUM } DisplaceType;
+typedef enum MuGiqBool_s { MUGIQ_BOOL_FALSE = 0, MUGIQ_BOOL_TRUE = 1, MUGIQ_BOOL_INVALID = MUGIQ_INVALID_ENUM } MuGiqBool;
+typedef enum DisplaceFlag_s {
+  DispFlagNone = MUGIQ_INVALID_ENUM,
+  DispFlag_X = 0, DispFlag_x = 1, DispFlag_Y = 2, DispFlag_y = 3, DispFlag_Z = 4, DispFlag_z = 5, DispFlag_T = 6, DispFlag_t = 7
+} DisplaceFlag;
+typedef enum DisplaceDir_s { DispDirNone = MUGIQ_INVALID_ENUM, DispDir_x = 0, DispDir_y = 1, DispDir_z = 2, DispDir_t = 3 } DisplaceDir;
+typedef enum DisplaceSign_s { DispSignNone = MUGIQ_INVALID_ENUM, DispSignMinus = 0, DispSignPlus = 1 } DisplaceSign;
+typedef enum MuGiqBoundaryDirection_s {
+  MUGIQ_BOUNDARY_BACKWARD = 0,
+  MUGIQ_BOUNDARY_FORWARD = 1,
+  MUGIQ_BOUNDARY_INVALID = MUGIQ_INVALID_ENUM
+} MuGiqBoundaryDirection;
+#endif
+
+namespace mugiq_hip {
+
+constexpr int FLOAT2_FIELD_ORDER = MUGIQ_HIP_FLOAT2_FIELD_ORDER;  // QUDA_FLOAT2_FIELD_ORDER
+constexpr int FLOAT4_FIELD_ORDER = MUGIQ_HIP_FLOAT4_FIELD_ORDER;  // QUDA_FLOAT4_FIELD_ORDER
+
+struct Error : std::runtime_error {
+  int status;
+  Error(int st, const std::string &msg) : std::runtime_error(msg), status(st) {}
+};
+inline void check(int status) {
+  if (status != 0) throw Error(status, mugiq_hip_last_error());
+}
+
+using ColorSpinorField = MugiqHipSpinorField;
+using GaugeField = MugiqHipGaugeField;
+
+template <typename Float> constexpr int precisionOf() {
+  static_assert(sizeof(Float) == 4 || sizeof(Float) == 8, "Float must be float or double");
+  return (int)sizeof(Float);
+}
+template <typename Float, int order> inline void checkField(const ColorSpinorField *f, const char *who) {
+  if (f->precision != precisionOf<Float>() || f->field_order != order)
+    throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, std::string(who) + ": field precision/order does not match the template arguments");
+}
+
+// lib/contract_wrappers.cu:6-19, 26-43
+template <typename Float> inline void copyGammaCoeffStructToSymbol() { check(mugiq_hip_copy_gamma_coeff_to_symbol(precisionOf<Float>())); }
+template <typename Float> inline void copyGammaMapStructToSymbol() { check(mugiq_hip_copy_gamma_map_to_symbol(precisionOf<Float>())); }
+
+// lib/contract_wrappers.cu:50-77 (commCoord replaces QUDA's comm_coord(); NULL = single process)
+template <typename Float>
+inline void createPhaseMatrixGPU(std::complex<Float> *phaseMatrix_d, const int *momMatrix_h, long long locV3, int Nmom, int FTSign,
+                                 const int localL[], const int totalL[], const int commCoord[] = nullptr, void *stream = nullptr) {
+  check(mugiq_hip_create_phase_matrix(phaseMatrix_d, momMatrix_h, locV3, Nmom, FTSign, localL, totalL, commCoord,
+                                      precisionOf<Float>(), stream));
+}
+
+// lib/contract_wrappers.cu:88-115
+template <typename Float, int fieldOrder>
+inline void performLoopContraction(std::complex<Float> *loopData_d, ColorSpinorField *eVecL, ColorSpinorField *eVecR, Float sigma,
+                                   void *stream = nullptr) {
+  checkField<Float, fieldOrder>(eVecL, "performLoopContraction");
+  checkField<Float, fieldOrder>(eVecR, "performLoopContraction");
+  check(mugiq_hip_perform_loop_contraction(loopData_d, eVecL, eVecR, (double)sigma, stream));
+}
+
+// the eigenvector loop of lib/loop_mugiq.cpp:478-503 in one launch (new)
+template <typename Float, int fieldOrder>
+inline void performLoopContractionBatched(std::complex<Float> *loopData_d, const std::vector<ColorSpinorField> &eVecL,
+                                          const std::vector<ColorSpinorField> &eVecR, const std::vector<double> &sigma,
+                                          void *stream = nullptr) {
+  if (eVecL.empty() || eVecL.size() != eVecR.size() || eVecL.size() != sigma.size())
+    throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "performLoopContractionBatched: size mismatch");
+  checkField<Float, fieldOrder>(&eVecL[0], "performLoopContractionBatched");
+  check(mugiq_hip_perform_loop_contraction_batched(loopData_d, eVecL.data(), eVecR.data(), sigma.data(), (int)eVecL.size(), stream));
+}
+
+// lib/contract_wrappers.cu:133-156
+template <typename Float>
+inline void convertIdxOrder_mapGamma(std::complex<Float> *dataPosMP_d, const std::complex<Float> *dataPos_d, int nData, int nLoop,
+                                     int nParity, int volumeCB, const int localL[], void *stream = nullptr) {
+  check(mugiq_hip_convert_idx_order_map_gamma(dataPosMP_d, dataPos_d, nData, nLoop, nParity, volumeCB, localL, precisionOf<Float>(),
+                                              stream));
+}
+
+// lib/contract_wrappers.cu:171-198 (the halo exchange of :166-169 is the caller's: fill src->ghost first)
+template <typename Float, int order>
+inline void performCovariantDisplacementVector(ColorSpinorField *dst, ColorSpinorField *src, GaugeField *gauge, DisplaceDir dispDir,
+                                               DisplaceSign dispSign, const int commDim[4] = nullptr, void *stream = nullptr) {
+  checkField<Float, order>(dst, "performCovariantDisplacementVector");
+  checkField<Float, order>(src, "performCovariantDisplacementVector");
+  check(mugiq_hip_perform_covariant_displacement_vector(dst, src, gauge, (int)dispDir, (int)dispSign, commDim, stream));
+}
+
+// the cublas{Z,C}gemm of lib/loop_mugiq.cpp:363-378
+template <typename Float>
+inline void momentumProjectionGemm(std::complex<Float> *dataMom_d, const std::complex<Float> *dataPosMP_d,
+                                   const std::complex<Float> *phaseMatrix_d, int locT, int nData, long long locV3, int Nmom,
+                                   void *stream = nullptr) {
+  check(mugiq_hip_momentum_projection(dataMom_d, dataPosMP_d, phaseMatrix_d, locT, nData, locV3, Nmom, precisionOf<Float>(), nullptr,
+                                      0, stream));
+}
+
+// include/gamma.h:11-20
+inline std::string GammaName(int m) {
+  const char *s = mugiq_hip_gamma_name(m);
+  if (!s) throw std::out_of_range("GammaName");
+  return s;
+}
+
+// include/mugiq.h:28-47 (the reference passes host QDP links + QudaGaugeParam; here the extended device field)
+struct MugiqLoopParam {
+  int Nmom = 0;
+  std::vector<std::vector<int>> momMatrix;  // [Nmom][3]
+  LoopFTSign FTSign = LOOP_FT_SIGN_PLUS;
+  LoopCalcType calcType = LOOP_CALC_TYPE_OPT_KERNEL;
+  MuGiqBool writeMomSpaceHDF5 = MUGIQ_BOOL_FALSE;
+  MuGiqBool writePosSpaceHDF5 = MUGIQ_BOOL_FALSE;
+  MuGiqBool doMomProj = MUGIQ_BOOL_FALSE;
+  MuGiqBool doNonLocal = MUGIQ_BOOL_FALSE;
+  std::vector<std::string> disp_entry;
+  std::vector<std::string> disp_str;
+  std::string fname_mom_h5;
+  std::string fname_pos_h5;
+  std::vector<int> disp_start;
+  std::vector<int> disp_stop;
+  const GaugeField *gauge = nullptr;
+};
+
+// tests/loop.cpp:656-705
+inline void setDisplaceEntryString(MugiqLoopParam &p, const std::string &entries) {
+  const int maxE = 64;
+  std::vector<char> strs(4 * maxE);
+  std::vector<int> a(maxE), b(maxE);
+  int n = mugiq_hip_parse_displace_entry_string(entries.c_str(), maxE, strs.data(), a.data(), b.data());
+  if (n < 0) check(-n);
+  p.disp_entry.clear();
+  p.disp_str.clear();
+  p.disp_start.assign(a.begin(), a.begin() + n);
+  p.disp_stop.assign(b.begin(), b.begin() + n);
+  size_t pos = 0;
+  for (int i = 0; i < n; i++) {
+    p.disp_str.emplace_back(&strs[4 * i]);
+    size_t semi = entries.find(';', pos);
+    p.disp_entry.push_back(entries.substr(pos, semi == std::string::npos ? std::string::npos : semi - pos));
+    pos = semi == std::string::npos ? entries.size() : semi + 1;
+  }
+  p.doNonLocal = MUGIQ_BOOL_TRUE;
+}
+
+// include/loop_mugiq.h:123-134: Loop_Mugiq(loopParams, eigsolve); computeCoarseLoop(); writeLoopsHDF5()
+// `eVecs` / `eVals_sigma` are what the reference reads from Eigsolve_Mugiq as a friend (lib/loop_mugiq.cpp:442,479).
+template <typename Float, int fieldOrder> class Loop_Mugiq {
+  MugiqHipLoop *h_ = nullptr;
+
+public:
+  Loop_Mugiq(MugiqLoopParam *lp, const std::vector<ColorSpinorField> &eVecs, const std::vector<double> &eVals_sigma,
+             const MugiqHipComm *comm = nullptr, void *stream = nullptr) {
+    if (eVecs.empty() || eVecs.size() != eVals_sigma.size()) throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "Loop_Mugiq: eVecs / eVals_sigma size mismatch");
+    checkField<Float, fieldOrder>(&eVecs[0], "Loop_Mugiq");
+    std::vector<int> mom;
+    for (auto &m : lp->momMatrix) {
+      if (m.size() != 3) throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "Loop_Mugiq: momMatrix rows must have 3 entries");
+      mom.insert(mom.end(), m.begin(), m.end());
+    }
+    std::vector<const char *> ent, str;
+    for (auto &s : lp->disp_entry) ent.push_back(s.c_str());
+    for (auto &s : lp->disp_str) str.push_back(s.c_str());
+    ent.resize(str.size(), "");
+    if (lp->disp_str.size() != lp->disp_start.size() || lp->disp_str.size() != lp->disp_stop.size())
+      throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "Displacement string length not compatible with displacement limits length");
+    MugiqHipLoopParam p{};
+    p.Nmom = lp->Nmom ? lp->Nmom : (int)lp->momMatrix.size();
+    p.momMatrix = mom.empty() ? nullptr : mom.data();
+    p.FTSign = (int)lp->FTSign;
+    p.calcType = (int)lp->calcType;
+    p.writeMomSpaceHDF5 = lp->writeMomSpaceHDF5 == MUGIQ_BOOL_TRUE;
+    p.writePosSpaceHDF5 = lp->writePosSpaceHDF5 == MUGIQ_BOOL_TRUE;
+    p.doMomProj = lp->doMomProj == MUGIQ_BOOL_TRUE;
+    p.doNonLocal = lp->doNonLocal == MUGIQ_BOOL_TRUE;
+    p.nDispEntries = (int)str.size();
+    p.disp_entry = ent.data();
+    p.disp_str = str.data();
+    p.disp_start = lp->disp_start.data();
+    p.disp_stop = lp->disp_stop.data();
+    p.fname_mom_h5 = lp->fname_mom_h5.c_str();
+    p.fname_pos_h5 = lp->fname_pos_h5.c_str();
+    p.gauge = lp->gauge;
+    check(mugiq_hip_loop_create(&h_, &p, eVecs.data(), eVals_sigma.data(), (int)eVecs.size(), comm, stream));
+  }
+  Loop_Mugiq(const Loop_Mugiq &) = delete;
+  Loop_Mugiq &operator=(const Loop_Mugiq &) = delete;
+  ~Loop_Mugiq() { mugiq_hip_loop_destroy(h_); }
+
+  void computeCoarseLoop() { check(mugiq_hip_loop_compute(h_)); }  // lib/loop_mugiq.cpp:439-525
+  void writeLoopsHDF5() { check(mugiq_hip_loop_write_hdf5(h_)); }  // lib/loop_mugiq.cpp:668-693
+
+  MugiqHipLoopInfo info() const {
+    MugiqHipLoopInfo i;
+    check(mugiq_hip_loop_get_info(h_, &i));
+    return i;
+  }
+  const std::complex<Float> *dataPos_d() const { return static_cast<const std::complex<Float> *>(mugiq_hip_loop_data_pos_d(h_)); }
+  const std::complex<Float> *dataPos() { return static_cast<const std::complex<Float> *>(mugiq_hip_loop_data_pos_h(h_)); }
+  const std::complex<Float> *dataMom_bcast() const { return static_cast<const std::complex<Float> *>(mugiq_hip_loop_data_mom_bcast_h(h_)); }
+};
+
+// lib/interface_mugiq.cpp:158-172: computeLoop<Float,fieldOrder>(loopParams, eigsolve)
+template <typename Float, int fieldOrder>
+inline void computeLoop(MugiqLoopParam loopParams, const std::vector<ColorSpinorField> &eVecs, const std::vector<double> &eVals_sigma,
+                        const MugiqHipComm *comm = nullptr, void *stream = nullptr) {
+  Loop_Mugiq<Float, fieldOrder> loop(&loopParams, eVecs, eVals_sigma, comm, stream);
+  loop.computeCoarseLoop();
+  if (loopParams.writeMomSpaceHDF5 != MUGIQ_BOOL_FALSE || loopParams.writePosSpaceHDF5 != MUGIQ_BOOL_FALSE) loop.writeLoopsHDF5();
+}
+
+}  // namespace mugiq_hip
+
+#endif  // MUGIQ_HIP_OPERATORS_HPP

@@ -1,0 +1,154 @@
+// C++ driver program over include/mugiq_hip_operators.hpp: the computeLoop flow of the reference's test driver
+// (tests/loop.cpp:751-936 -> lib/interface_mugiq.cpp:158-172) for BASELINE.json configs[0]: 8^4, unit gauge,
+// N_ev = 4, ultra-local loop (+ optional displacements), one process.  QUDA's eigensolver is out of scope, so the
+// eigenvectors are synthetic (seeded Gaussian, unit norm; sigma_n = 0.01 + 0.002 n) -- SURVEY.md section 8c.
+//
+// Accepts the reference's loop flags (tests/test_params_mugiq.cpp:77-112):
+//   --dim x y z t  --nev N  --loop-ft-sign plus|minus  --loop-calc-type blas|opt|basic  --loop-do-momproj yes|no
+//   --loop-do-nonlocal yes|no  --displace-entry-string "+z:1,8;-x:3"  --momenta-filename FILE
+//   --loop-write-mom-space yes|no  --loop-mom-space-filename FILE  --check (compare with the C oracle, exit code)
+#include <hip/hip_runtime.h>
+
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "mugiq_hip_operators.hpp"
+
+using namespace mugiq_hip;
+typedef std::complex<double> cplx;
+
+// checker (tests only): plain-C restatement of the reference kernel, oracle/mugiq_oracle.c
+extern "C" void oracle_loop_contract_f64(void *loop, const void *const *vL, const void *const *vR, const double *sigma, int nVec,
+                                          long long site_begin, long long site_end, int volumeCB, long long stride,
+                                          long long parity_offset, int order);
+
+#define HIPCHK(x)                                                                      \
+  do {                                                                                 \
+    hipError_t e = (x);                                                                \
+    if (e != hipSuccess) {                                                             \
+      fprintf(stderr, "%s failed: %s\n", #x, hipGetErrorString(e));                    \
+      return 2;                                                                        \
+    }                                                                                  \
+  } while (0)
+
+static bool yes(const std::string &s) { return s == "yes" || s == "true" || s == "1"; }
+
+int main(int argc, char **argv) {
+  int X[4] = {8, 8, 8, 8};
+  int nev = 4;
+  bool check = false;
+  std::string momFile;
+  MugiqLoopParam lp;
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    auto next = [&]() -> std::string { return i + 1 < argc ? argv[++i] : ""; };
+    if (a == "--dim") for (int d = 0; d < 4; d++) X[d] = atoi(next().c_str());
+    else if (a == "--nev") nev = atoi(next().c_str());
+    else if (a == "--loop-ft-sign") lp.FTSign = next() == "minus" ? LOOP_FT_SIGN_MINUS : LOOP_FT_SIGN_PLUS;
+    else if (a == "--loop-calc-type") { std::string v = next(); lp.calcType = v == "basic" ? LOOP_CALC_TYPE_BASIC_KERNEL : v == "blas" ? LOOP_CALC_TYPE_BLAS : LOOP_CALC_TYPE_OPT_KERNEL; }
+    else if (a == "--loop-do-momproj") lp.doMomProj = yes(next()) ? MUGIQ_BOOL_TRUE : MUGIQ_BOOL_FALSE;
+    else if (a == "--loop-do-nonlocal") lp.doNonLocal = yes(next()) ? MUGIQ_BOOL_TRUE : MUGIQ_BOOL_FALSE;
+    else if (a == "--displace-entry-string") setDisplaceEntryString(lp, next());
+    else if (a == "--momenta-filename") momFile = next();
+    else if (a == "--loop-write-mom-space") lp.writeMomSpaceHDF5 = yes(next()) ? MUGIQ_BOOL_TRUE : MUGIQ_BOOL_FALSE;
+    else if (a == "--loop-mom-space-filename") lp.fname_mom_h5 = next();
+    else if (a == "--check") check = true;
+    else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+  }
+  if (lp.doMomProj == MUGIQ_BOOL_TRUE) {  // tests/loop.cpp:724-740: one "px py pz" triple per line
+    std::ifstream f(momFile);
+    if (!f) { fprintf(stderr, "Cannot open file %s to read momenta (option --momenta-filename)\n", momFile.c_str()); return 2; }
+    std::string line;
+    while (std::getline(f, line)) {
+      std::istringstream iss(line);
+      std::vector<int> m(3);
+      if (iss >> m[0] >> m[1] >> m[2]) lp.momMatrix.push_back(m);
+      else { fprintf(stderr, "Incorrect file format in Line %zu\n", lp.momMatrix.size()); return 2; }
+    }
+    lp.Nmom = (int)lp.momMatrix.size();
+  }
+  const int V = X[0] * X[1] * X[2] * X[3], vcb = V / 2;
+  const size_t per = (size_t)24 * vcb;  // complex per field
+
+  // synthetic eigenvectors, FLOAT2 order, pad 0
+  std::mt19937_64 rng(777);
+  std::normal_distribution<double> gauss;
+  std::vector<std::vector<cplx>> hv(nev, std::vector<cplx>(per));
+  std::vector<ColorSpinorField> eVecs(nev);
+  std::vector<double> sigma(nev);
+  std::vector<void *> dptr(nev);
+  for (int n = 0; n < nev; n++) {
+    double nrm = 0;
+    for (auto &z : hv[n]) { z = cplx(gauss(rng), gauss(rng)); nrm += std::norm(z); }
+    for (auto &z : hv[n]) z /= std::sqrt(nrm);
+    HIPCHK(hipMalloc(&dptr[n], per * sizeof(cplx)));
+    HIPCHK(hipMemcpy(dptr[n], hv[n].data(), per * sizeof(cplx), hipMemcpyHostToDevice));
+    ColorSpinorField f{};
+    f.data = dptr[n]; f.precision = 8; f.field_order = FLOAT2_FIELD_ORDER; f.nParity = 2; f.volumeCB = vcb; f.stride = vcb;
+    f.parity_offset = (int64_t)12 * vcb;
+    for (int d = 0; d < 4; d++) f.X[d] = X[d];
+    eVecs[n] = f;
+    sigma[n] = 0.01 + 0.002 * n;
+  }
+  // unit gauge (configs[0]), single domain: R = 0, built through Displace's setup path from QDP-ordered host links
+  GaugeField g{};
+  std::vector<double> qdp((size_t)V * 18, 0.0);
+  for (int s = 0; s < V; s++) qdp[(size_t)s * 18 + 0] = qdp[(size_t)s * 18 + 8] = qdp[(size_t)s * 18 + 16] = 1.0;
+  const void *links[4] = {qdp.data(), qdp.data(), qdp.data(), qdp.data()};
+  if (lp.doNonLocal == MUGIQ_BOOL_TRUE) {
+    int R[4] = {0, 0, 0, 0};
+    g.precision = 8; g.stride = vcb; g.parity_offset = (int64_t)36 * vcb;
+    for (int d = 0; d < 4; d++) { g.X[d] = X[d]; g.R[d] = 0; }
+    HIPCHK(hipMalloc(&g.data, mugiq_hip_extended_gauge_bytes(X, R, 8)));
+    try { mugiq_hip::check(mugiq_hip_create_extended_gauge(&g, links, 8, nullptr, nullptr)); }
+    catch (const Error &e) { fprintf(stderr, "%s\n", e.what()); return 1; }
+    lp.gauge = &g;
+  }
+
+  int rc = 0;
+  try {
+    Loop_Mugiq<double, FLOAT2_FIELD_ORDER> loop(&lp, eVecs, sigma);
+    loop.computeCoarseLoop();
+    if (lp.writeMomSpaceHDF5 == MUGIQ_BOOL_TRUE) loop.writeLoopsHDF5();
+    MugiqHipLoopInfo info = loop.info();
+    printf("computeLoop: lattice %d %d %d %d, N_ev = %d, nLoop = %d, Nmom = %d\n", X[0], X[1], X[2], X[3], nev, info.nLoop, info.Nmom);
+    if (check) {
+      // ultra-local slot vs the C oracle; Gamma = 1 slot sums to sum_n 1/sigma_n
+      std::vector<cplx> ref((size_t)16 * V, 0.0);
+      std::vector<const void *> ptrs(nev);
+      for (int n = 0; n < nev; n++) ptrs[n] = hv[n].data();
+      oracle_loop_contract_f64(ref.data(), ptrs.data(), ptrs.data(), sigma.data(), nev, 0, V, vcb, vcb, 12LL * vcb, 2);
+      const cplx *pos = loop.dataPos();
+      double err = 0, mx = 0, s1 = 0, expect = 0;
+      for (size_t i = 0; i < ref.size(); i++) { err = std::max(err, std::abs(pos[i] - ref[i])); mx = std::max(mx, std::abs(ref[i])); }
+      for (int i = 0; i < V; i++) s1 += pos[i].real();
+      for (int n = 0; n < nev; n++) expect += 1.0 / sigma[n];
+      printf("ultra-local max rel err vs C oracle: %.3e ; sum_x L_1(x) = %.12e (expected %.12e)\n", err / mx, s1, expect);
+      if (err / mx > 1e-12 || std::abs(s1 - expect) > 1e-10 * expect) rc = 1;
+      if (lp.doMomProj == MUGIQ_BOOL_TRUE) {  // p = 0 of the g5 channel (output slot 15 <- T(0), sign +) = sum over space of L_1
+        for (int im = 0; im < info.Nmom; im++)
+          if (lp.momMatrix[im][0] == 0 && lp.momMatrix[im][1] == 0 && lp.momMatrix[im][2] == 0) {
+            const cplx *mom = loop.dataMom_bcast();
+            double tsum = 0;
+            for (int t = 0; t < info.totT; t++) tsum += mom[t + (long long)info.locT * 15 + (long long)info.locT * 16 * info.nLoop * im].real();
+            printf("p=0, g5 channel, summed over t: %.12e (expected %.12e)\n", tsum, expect);
+            if (std::abs(tsum - expect) > 1e-10 * expect) rc = 1;
+          }
+      }
+    }
+  } catch (const Error &e) {
+    fprintf(stderr, "mugiq_hip error %d: %s\n", e.status, e.what());
+    rc = 1;
+  }
+  for (void *p : dptr) (void)hipFree(p);
+  if (g.data) (void)hipFree(g.data);
+  printf(rc == 0 ? "LOOP TEST PASSED\n" : "LOOP TEST FAILED\n");
+  return rc;
+}
