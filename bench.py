@@ -46,10 +46,11 @@ def parse():
     return ap.parse_args()
 
 
-def make_evecs(hip, X, nev, prec, order, device, seed):
-    """N_ev synthetic eigenvectors in one HBM allocation (native layout), each globally unit-norm."""
+def make_evecs(hip, X, nev, prec, order, device, seed, pad=0):
+    """N_ev synthetic eigenvectors in one HBM allocation (native layout, Stride() = volumeCB + pad), each unit-norm
+    (the pad sites carry random numbers too; they are never addressed)."""
     vcb = int(np.prod(X)) // 2
-    per = 2 * 12 * vcb
+    per = 2 * 12 * (vcb + pad)
     cdt = torch.complex128 if prec == 8 else torch.complex64
     big = torch.empty(nev * per, dtype=cdt, device=device)
     g = torch.Generator(device=device)
@@ -62,7 +63,7 @@ def make_evecs(hip, X, nev, prec, order, device, seed):
         w = torch.complex(re, im)
         w /= torch.linalg.vector_norm(w)
         v.copy_(w.to(cdt))
-        fields.append(hip.SpinorField(X, prec, order, data=v))
+        fields.append(hip.SpinorField(X, prec, order, pad=pad, data=v))
         del re, im, w
     return big, fields
 
@@ -109,12 +110,20 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
+    backend = os.environ.get("MUGIQ_BENCH_BACKEND", "nccl")      # "gloo" only to rehearse N>1 on a one-GPU box
+    dev_index = local_rank if backend == "nccl" else local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)     # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     import mugiq_amd as hip            # raises if libmugiq_hip.so is missing: there is no fallback
 
@@ -152,7 +161,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # ---------------------------------------------------------------------------------------------------
     kern_ms = float(np.mean([ev0[i].elapsed_time(ev1[i]) for i in range(a.steps)]))
-    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = float(t[0]), float(t[1])

@@ -99,6 +99,11 @@ const char *mugiq_hip_last_error(void);
 /* number of visible HIP devices (0 if none); does not initialise a context */
 int mugiq_hip_device_count(void);
 
+/* Roofline calibration (measurement aid, not part of the reference): stream-read `bytes` of buf_d once with 16-B
+ * loads per lane (plain or non-temporal) and write nothing.  Time it with events to get the achievable HBM read
+ * bandwidth of the device at hand. */
+int mugiq_hip_probe_read_bandwidth(const void *buf_d, size_t bytes, int nonTemporal, void *stream);
+
 /* ---- gamma tables ------------------------------------------------------------------------------- */
 /* copyGammaCoeffStructToSymbol<Float>()  lib/contract_wrappers.cu:6-19
  * copyGammaMapStructToSymbol<Float>()    lib/contract_wrappers.cu:26-43

@@ -14,11 +14,11 @@
 // Hermitian and only its upper triangle is accumulated.
 #include "internal.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace mugiq {
 
-constexpr int kContractBlock = 256;
 
 template <typename F> struct ContractArgs {
   Cplx<F> *loop;           // [16][V]
@@ -68,10 +68,50 @@ template <typename F> __device__ inline void accumulate_herm(F diag[4], Cplx<F> 
     }
 }
 
-template <typename F, int ORDER, bool SAME>
-__global__ __launch_bounds__(kContractBlock) void loop_contract_kernel(ContractArgs<F> a) {
+// streaming load of one site's 12 complex; NT = non-temporal (the eigenvectors are read exactly once)
+template <typename F, int ORDER, bool NT>
+__device__ inline void load_spinor(Cplx<F> v[12], const void *body, int64_t parity_offset, int stride, int parity, int x_cb) {
+  typedef F vec2 __attribute__((ext_vector_type(2)));
+  typedef F vec4 __attribute__((ext_vector_type(4)));
+  const Cplx<F> *p = static_cast<const Cplx<F> *>(body) + parity * parity_offset;
+  if constexpr (ORDER == 2) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      const vec2 *q = reinterpret_cast<const vec2 *>(p + (int64_t)k * stride + x_cb);
+      vec2 t = NT ? __builtin_nontemporal_load(q) : *q;
+      v[k] = Cplx<F>{t.x, t.y};
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const vec4 *q = reinterpret_cast<const vec4 *>(p + ((int64_t)j * stride + x_cb) * 2);
+      vec4 t = NT ? __builtin_nontemporal_load(q) : *q;
+      v[2 * j] = Cplx<F>{t.x, t.y};
+      v[2 * j + 1] = Cplx<F>{t.z, t.w};
+    }
+  }
+}
+
+// trace = sum_{s2} row_value[iG][s2] * resG[s2][column_index[iG][s2]]; loopData[tid + V*iG] += trace (:110-120)
+template <typename F> __device__ inline void trace_and_store(Cplx<F> *loop, const Cplx<F> acc[16], int V, int site) {
+#pragma unroll
+  for (int iG = 0; iG < 16; iG++) {
+    Cplx<F> t{F(0), F(0)};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++) add_phase(t, kGammaPhase[iG][s2], acc[s2 * 4 + kGammaColumn[iG][s2]]);
+    Cplx<F> *out = loop + (int64_t)V * iG + site;
+    Cplx<F> o = *out;
+    o.re += t.re;
+    o.im += t.im;
+    *out = o;
+  }
+}
+
+// DEPTH eigenvectors are in flight per lane (DEPTH-1 loads issued ahead of the one being consumed).
+template <typename F, int ORDER, bool SAME, int BLOCK, int DEPTH, bool NT>
+__global__ __launch_bounds__(BLOCK) void loop_contract_kernel(ContractArgs<F> a) {
   const int V = 2 * a.volumeCB;
-  const int site = blockIdx.x * kContractBlock + threadIdx.x;  // tid = x_cb + parity*volumeCB  (:52)
+  const int site = blockIdx.x * BLOCK + threadIdx.x;  // tid = x_cb + parity*volumeCB  (:52)
   if (site >= V) return;
   const int parity = site >= a.volumeCB ? 1 : 0;
   const int x_cb = site - parity * a.volumeCB;
@@ -80,25 +120,26 @@ __global__ __launch_bounds__(kContractBlock) void loop_contract_kernel(ContractA
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = Cplx<F>{F(0), F(0)};
 
-  auto view = [&](const void *const *tab, int n) {
-    return SpinorView<F, ORDER>{const_cast<F *>(static_cast<const F *>(tab[n])), a.stride, a.parity_offset};
-  };
-
   if constexpr (SAME) {
     F diag[4] = {F(0), F(0), F(0), F(0)};
     Cplx<F> up[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) up[i] = Cplx<F>{F(0), F(0)};
-    Cplx<F> vA[12], vB[12];
-    int n = 0;
-    view(a.L, 0).load(vA, parity, x_cb);
-    for (; n + 1 < a.nVec; n += 2) {  // two eigenvectors per trip: the next load is in flight while one is consumed
-      view(a.L, n + 1).load(vB, parity, x_cb);
-      accumulate_herm(diag, up, vA, a.inv_sigma[n]);
-      if (n + 2 < a.nVec) view(a.L, n + 2).load(vA, parity, x_cb);
-      accumulate_herm(diag, up, vB, a.inv_sigma[n + 1]);
+    Cplx<F> v[DEPTH][12];
+#pragma unroll
+    for (int j = 0; j < DEPTH - 1; j++)
+      if (j < a.nVec) load_spinor<F, ORDER, NT>(v[j], a.L[j], a.parity_offset, a.stride, parity, x_cb);
+    for (int n = 0; n < a.nVec; n += DEPTH) {
+#pragma unroll
+      for (int j = 0; j < DEPTH; j++) {
+        const int m = n + j;
+        if (m < a.nVec) {
+          const int pre = m + DEPTH - 1;
+          if (pre < a.nVec) load_spinor<F, ORDER, NT>(v[(j + DEPTH - 1) % DEPTH], a.L[pre], a.parity_offset, a.stride, parity, x_cb);
+          accumulate_herm(diag, up, v[j], a.inv_sigma[m]);
+        }
+      }
     }
-    if (n < a.nVec) accumulate_herm(diag, up, vA, a.inv_sigma[n]);
     int p = 0;
 #pragma unroll
     for (int be = 0; be < 4; be++) {
@@ -111,34 +152,73 @@ __global__ __launch_bounds__(kContractBlock) void loop_contract_kernel(ContractA
       }
     }
   } else {
-    Cplx<F> lA[12], rA[12], lB[12], rB[12];
-    int n = 0;
-    view(a.L, 0).load(lA, parity, x_cb);
-    view(a.R, 0).load(rA, parity, x_cb);
-    for (; n + 1 < a.nVec; n += 2) {
-      view(a.L, n + 1).load(lB, parity, x_cb);
-      view(a.R, n + 1).load(rB, parity, x_cb);
-      accumulate_full(acc, lA, rA, a.inv_sigma[n]);
-      if (n + 2 < a.nVec) {
-        view(a.L, n + 2).load(lA, parity, x_cb);
-        view(a.R, n + 2).load(rA, parity, x_cb);
+    Cplx<F> l[DEPTH][12], r[DEPTH][12];
+#pragma unroll
+    for (int j = 0; j < DEPTH - 1; j++)
+      if (j < a.nVec) {
+        load_spinor<F, ORDER, NT>(l[j], a.L[j], a.parity_offset, a.stride, parity, x_cb);
+        load_spinor<F, ORDER, NT>(r[j], a.R[j], a.parity_offset, a.stride, parity, x_cb);
       }
-      accumulate_full(acc, lB, rB, a.inv_sigma[n + 1]);
+    for (int n = 0; n < a.nVec; n += DEPTH) {
+#pragma unroll
+      for (int j = 0; j < DEPTH; j++) {
+        const int m = n + j;
+        if (m < a.nVec) {
+          const int pre = m + DEPTH - 1;
+          if (pre < a.nVec) {
+            load_spinor<F, ORDER, NT>(l[(j + DEPTH - 1) % DEPTH], a.L[pre], a.parity_offset, a.stride, parity, x_cb);
+            load_spinor<F, ORDER, NT>(r[(j + DEPTH - 1) % DEPTH], a.R[pre], a.parity_offset, a.stride, parity, x_cb);
+          }
+          accumulate_full(acc, l[j], r[j], a.inv_sigma[m]);
+        }
+      }
     }
-    if (n < a.nVec) accumulate_full(acc, lA, rA, a.inv_sigma[n]);
   }
+  trace_and_store(a.loop, acc, V, site);
+}
 
-  // trace = sum_{s2} row_value[iG][s2] * resG[s2][column_index[iG][s2]]; loopData[tid + V*iG] += trace (:110-120)
-#pragma unroll
-  for (int iG = 0; iG < 16; iG++) {
-    Cplx<F> t{F(0), F(0)};
-#pragma unroll
-    for (int s2 = 0; s2 < 4; s2++) add_phase(t, kGammaPhase[iG][s2], acc[s2 * 4 + kGammaColumn[iG][s2]]);
-    Cplx<F> *out = a.loop + (int64_t)V * iG + site;
-    Cplx<F> o = *out;
-    o.re += t.re;
-    o.im += t.im;
-    *out = o;
+// Launch configuration.  Defaults were picked by sweeping on MI355X (profiles/); MUGIQ_HIP_CONTRACT_TUNE="block,depth,nt"
+// overrides them for experiments (e.g. "512,3,1").
+struct ContractTune {
+  int block, depth, nt;
+};
+static ContractTune contract_tune(bool same) {
+  // sweep on MI355X, 32^4 x 200 fp64 (profiles/r01_contract_sweep.txt): non-temporal loads +4 %; block size and prefetch
+  // depth within 1 % of each other (4-6 waves/SIMD already cover the latency), so the leanest variant is the default
+  ContractTune t{256, 1, 1};
+  if (const char *e = getenv("MUGIQ_HIP_CONTRACT_TUNE")) {
+    int b = 0, d = 0, n = 0;
+    if (sscanf(e, "%d,%d,%d", &b, &d, &n) == 3 && (b == 64 || b == 128 || b == 256 || b == 512) && d >= 1 && d <= 3 && (n == 0 || n == 1)) {
+      t.block = b;
+      t.depth = (!same && d > 2) ? 2 : d;
+      t.nt = n;
+    }
+  }
+  return t;
+}
+
+template <typename F, int ORDER, bool SAME, int BLOCK, int DEPTH>
+static void launch_variant(const ContractArgs<F> &a, int nt, hipStream_t stream) {
+  const int V = 2 * a.volumeCB;
+  const dim3 grid((V + BLOCK - 1) / BLOCK), block(BLOCK);
+  if (nt) hipLaunchKernelGGL((loop_contract_kernel<F, ORDER, SAME, BLOCK, DEPTH, true>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((loop_contract_kernel<F, ORDER, SAME, BLOCK, DEPTH, false>), grid, block, 0, stream, a);
+}
+
+template <typename F, int ORDER, bool SAME, int BLOCK>
+static void launch_depth(const ContractArgs<F> &a, const ContractTune &t, hipStream_t stream) {
+  if (t.depth == 1) launch_variant<F, ORDER, SAME, BLOCK, 1>(a, t.nt, stream);
+  else if (t.depth == 2 || !SAME) launch_variant<F, ORDER, SAME, BLOCK, 2>(a, t.nt, stream);
+  else launch_variant<F, ORDER, SAME, BLOCK, (SAME ? 3 : 2)>(a, t.nt, stream);
+}
+
+template <typename F, int ORDER, bool SAME>
+static void launch_block(const ContractArgs<F> &a, const ContractTune &t, hipStream_t stream) {
+  switch (t.block) {
+  case 64: launch_depth<F, ORDER, SAME, 64>(a, t, stream); break;
+  case 128: launch_depth<F, ORDER, SAME, 128>(a, t, stream); break;
+  case 512: launch_depth<F, ORDER, SAME, 512>(a, t, stream); break;
+  default: launch_depth<F, ORDER, SAME, 256>(a, t, stream); break;
   }
 }
 
@@ -171,12 +251,9 @@ static int launch_contract(void *loop_d, const MugiqHipSpinorField *L, const Mug
   a.volumeCB = L[0].volumeCB;
   a.stride = L[0].stride;
   a.parity_offset = L[0].parity_offset;
-  const int V = 2 * a.volumeCB;
-  const dim3 grid((V + kContractBlock - 1) / kContractBlock), block(kContractBlock);
-  if (same)
-    hipLaunchKernelGGL((loop_contract_kernel<F, ORDER, true>), grid, block, 0, stream, a);
-  else
-    hipLaunchKernelGGL((loop_contract_kernel<F, ORDER, false>), grid, block, 0, stream, a);
+  const ContractTune t = contract_tune(same);
+  if (same) launch_block<F, ORDER, true>(a, t, stream);
+  else launch_block<F, ORDER, false>(a, t, stream);
   MUGIQ_CHECK_HIP(hipGetLastError());
   return MUGIQ_HIP_SUCCESS;
 }

@@ -96,6 +96,27 @@ __global__ __launch_bounds__(kUtilBlock) void convert_idx_map_gamma_kernel(Cplx<
   }
 }
 
+// ---- roofline calibration: a pure streaming read of `n16` 16-byte words (what "achievable HBM read bandwidth" means
+// on the device at hand).  Every lane keeps 8 independent 16-B loads in flight; the xor-sum is stored by one lane only
+// if it hits an impossible value, so the loads cannot be optimised away and nothing is written.
+template <bool NT>
+__global__ __launch_bounds__(256) void read_probe_kernel(const uint4 *buf, size_t n16, unsigned *sink) {
+  typedef unsigned vec4u __attribute__((ext_vector_type(4)));
+  const vec4u *p = reinterpret_cast<const vec4u *>(buf);
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  vec4u acc = {0, 0, 0, 0};
+  for (; i + 7 * stride < n16; i += 8 * stride) {
+    vec4u t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) t[j] = NT ? __builtin_nontemporal_load(p + i + j * stride) : p[i + j * stride];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc ^= t[j];
+  }
+  for (; i < n16; i += stride) acc ^= (NT ? __builtin_nontemporal_load(p + i) : p[i]);
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u && threadIdx.x == 0 && blockIdx.x == 12345678u) *sink = acc.x;
+}
+
 template <typename F>
 static int launch_phase(void *ph, const int *mom_h, long long locV3, int Nmom, int FTSign, const int localL[4],
                         const int totalL[4], const int commCoord[4], hipStream_t stream) {
@@ -156,6 +177,23 @@ int mugiq_hip_create_phase_matrix(void *phaseMatrix_d, const int *momMatrix_h, l
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (precision == 8) return launch_phase<double>(phaseMatrix_d, momMatrix_h, locV3, Nmom, FTSign, localL, totalL, commCoord, s);
   return launch_phase<float>(phaseMatrix_d, momMatrix_h, locV3, Nmom, FTSign, localL, totalL, commCoord, s);
+}
+
+int mugiq_hip_probe_read_bandwidth(const void *buf_d, size_t bytes, int nonTemporal, void *stream) {
+  MUGIQ_REQUIRE(buf_d != nullptr && bytes >= 16 && (reinterpret_cast<uintptr_t>(buf_d) & 15) == 0,
+                "mugiq_hip_probe_read_bandwidth: need a 16-byte aligned buffer of >= 16 bytes");
+  void *sink = nullptr;
+  int st = device_scratch(&sink, 64);
+  if (st) return st;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t n16 = bytes / 16;
+  const unsigned grid = 256 * 16;  // 16 workgroups of 256 lanes per CU
+  if (nonTemporal)
+    hipLaunchKernelGGL((read_probe_kernel<true>), dim3(grid), dim3(256), 0, s, static_cast<const uint4 *>(buf_d), n16, static_cast<unsigned *>(sink));
+  else
+    hipLaunchKernelGGL((read_probe_kernel<false>), dim3(grid), dim3(256), 0, s, static_cast<const uint4 *>(buf_d), n16, static_cast<unsigned *>(sink));
+  MUGIQ_CHECK_HIP(hipGetLastError());
+  return MUGIQ_HIP_SUCCESS;
 }
 
 int mugiq_hip_convert_idx_order_map_gamma(void *dataPosMP_d, const void *dataPos_d, int nData, int nLoop, int nParity,

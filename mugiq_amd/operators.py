@@ -137,3 +137,8 @@ def displacedLoopContractionFused(loopData_d, eVecs, sigmas, pathLinkFields, kVa
     _lib.check(_lib.load().mugiq_hip_displaced_loop_contraction_fused(
         loopData_d.data_ptr(), d, sg, n, links, kv, nk, int(dispDir), int(dispSign), _lib.int4(commDim),
         ghostLayers_d.data_ptr() if ghostLayers_d is not None else None, int(layers), _stream()))
+
+
+def probeReadBandwidth(buf, nonTemporal=False):
+    """Enqueue one streaming read of `buf` (a torch tensor); time it with events for the device's achievable GB/s."""
+    _lib.check(_lib.load().mugiq_hip_probe_read_bandwidth(buf.data_ptr(), buf.numel() * buf.element_size(), int(nonTemporal), _stream()))
