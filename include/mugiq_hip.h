@@ -134,6 +134,14 @@ int mugiq_hip_perform_loop_contraction_batched(void *loopData_d, const MugiqHipS
                                                const MugiqHipSpinorField *eVecR_h, const double *sigma_h,
                                                int nVec, void *stream);
 
+/* Mixed precision (BASELINE.json configs[3]; beyond the reference, which is single-typed end to end): loopPrecision = 8
+ * with fp32 eigenvectors keeps the storage in fp32 and does all arithmetic, the 16-gamma accumulation over the
+ * eigenvectors and the loop buffer in fp64.  loopPrecision = 0 or = the fields' precision is the plain call. */
+int mugiq_hip_perform_loop_contraction_batched_mixed(void *loopData_d, int loopPrecision,
+                                                     const MugiqHipSpinorField *eVecL_h,
+                                                     const MugiqHipSpinorField *eVecR_h, const double *sigma_h,
+                                                     int nVec, void *stream);
+
 /* ---- a4/a5  covariant displacement --------------------------------------------------------------------- */
 /* performCovariantDisplacementVector<Float,order>(dst, src, gauge, dispDir, dispSign)
  * lib/contract_wrappers.cu:171-198, kernel lib/mugiq_displace_kernels.cu:156-185:
@@ -175,6 +183,12 @@ int mugiq_hip_displaced_loop_contraction_fused(void *loopData_d, const MugiqHipS
                                                const int *kValues_h, int nK, int dispDir, int dispSign,
                                                const int commDim[4], const void *ghostLayers_d, int layers,
                                                void *stream);
+
+int mugiq_hip_displaced_loop_contraction_fused_mixed(void *loopData_d, int loopPrecision,
+                                                     const MugiqHipSpinorField *eVecs_h, const double *sigma_h, int nVec,
+                                                     const void *const *pathLinkFields_h, const int *kValues_h, int nK,
+                                                     int dispDir, int dispSign, const int commDim[4],
+                                                     const void *ghostLayers_d, int layers, void *stream);
 
 /* ---- a8  Fourier phase matrix -------------------------------------------------------------------------- */
 /* createPhaseMatrixGPU<Float>(phaseMatrix_d, momMatrix_h, locV3, Nmom, FTSign, localL, totalL)
@@ -254,12 +268,14 @@ typedef struct MugiqHipLoopParam_s {
   const char *fname_mom_h5;
   const char *fname_pos_h5;
   const MugiqHipGaugeField *gauge;
+  int loopPrecision;             /* not in the reference: 0 = the eigenvectors' precision; 8 with fp32 eigenvectors = mixed
+                                    precision (fp32 storage, fp64 accumulation, loop buffers, FT and output) */
 } MugiqHipLoopParam;
 
 /* Loop_Mugiq::LoopComputeParam + the element counts of allocateDataMemory
  * (include/loop_mugiq.h:141-271, lib/loop_mugiq.cpp:101-109) */
 typedef struct MugiqHipLoopInfo_s {
-  int nDispEntries, nLoop, nData, Nmom, precision, field_order;
+  int nDispEntries, nLoop, nData, Nmom, precision, field_order, loopPrecision;
   int localL[4], totalL[4];
   int locT, totT;
   long long locV4, locV3, totV3;

@@ -15,16 +15,19 @@
 #include "internal.h"
 
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace mugiq {
 
 
-template <typename F> struct ContractArgs {
-  Cplx<F> *loop;           // [16][V]
+// F = storage type of the eigenvectors, A = arithmetic / accumulation type (= F, or double over float storage:
+// the mixed-precision mode of BASELINE.json configs[3])
+template <typename A> struct ContractArgs {
+  Cplx<A> *loop;           // [16][V]
   const void *const *L;    // device table: nVec field bodies
   const void *const *R;    // device table (unused when SAME)
-  const F *inv_sigma;      // device [nVec]
+  const A *inv_sigma;      // device [nVec]
   int nVec;
   int volumeCB;
   int stride;
@@ -69,8 +72,8 @@ template <typename F> __device__ inline void accumulate_herm(F diag[4], Cplx<F> 
 }
 
 // streaming load of one site's 12 complex; NT = non-temporal (the eigenvectors are read exactly once)
-template <typename F, int ORDER, bool NT>
-__device__ inline void load_spinor(Cplx<F> v[12], const void *body, int64_t parity_offset, int stride, int parity, int x_cb) {
+template <typename F, typename A, int ORDER, bool NT>
+__device__ inline void load_spinor(Cplx<A> v[12], const void *body, int64_t parity_offset, int stride, int parity, int x_cb) {
   typedef F vec2 __attribute__((ext_vector_type(2)));
   typedef F vec4 __attribute__((ext_vector_type(4)));
   const Cplx<F> *p = static_cast<const Cplx<F> *>(body) + parity * parity_offset;
@@ -79,15 +82,15 @@ __device__ inline void load_spinor(Cplx<F> v[12], const void *body, int64_t pari
     for (int k = 0; k < 12; k++) {
       const vec2 *q = reinterpret_cast<const vec2 *>(p + (int64_t)k * stride + x_cb);
       vec2 t = NT ? __builtin_nontemporal_load(q) : *q;
-      v[k] = Cplx<F>{t.x, t.y};
+      v[k] = Cplx<A>{(A)t.x, (A)t.y};
     }
   } else {
 #pragma unroll
     for (int j = 0; j < 6; j++) {
       const vec4 *q = reinterpret_cast<const vec4 *>(p + ((int64_t)j * stride + x_cb) * 2);
       vec4 t = NT ? __builtin_nontemporal_load(q) : *q;
-      v[2 * j] = Cplx<F>{t.x, t.y};
-      v[2 * j + 1] = Cplx<F>{t.z, t.w};
+      v[2 * j] = Cplx<A>{(A)t.x, (A)t.y};
+      v[2 * j + 1] = Cplx<A>{(A)t.z, (A)t.w};
     }
   }
 }
@@ -108,34 +111,34 @@ template <typename F> __device__ inline void trace_and_store(Cplx<F> *loop, cons
 }
 
 // DEPTH eigenvectors are in flight per lane (DEPTH-1 loads issued ahead of the one being consumed).
-template <typename F, int ORDER, bool SAME, int BLOCK, int DEPTH, bool NT>
-__global__ __launch_bounds__(BLOCK) void loop_contract_kernel(ContractArgs<F> a) {
+template <typename F, typename A, int ORDER, bool SAME, int BLOCK, int DEPTH, bool NT>
+__global__ __launch_bounds__(BLOCK) void loop_contract_kernel(ContractArgs<A> a) {
   const int V = 2 * a.volumeCB;
   const int site = blockIdx.x * BLOCK + threadIdx.x;  // tid = x_cb + parity*volumeCB  (:52)
   if (site >= V) return;
   const int parity = site >= a.volumeCB ? 1 : 0;
   const int x_cb = site - parity * a.volumeCB;
 
-  Cplx<F> acc[16];
+  Cplx<A> acc[16];
 #pragma unroll
-  for (int i = 0; i < 16; i++) acc[i] = Cplx<F>{F(0), F(0)};
+  for (int i = 0; i < 16; i++) acc[i] = Cplx<A>{A(0), A(0)};
 
   if constexpr (SAME) {
-    F diag[4] = {F(0), F(0), F(0), F(0)};
-    Cplx<F> up[6];
+    A diag[4] = {A(0), A(0), A(0), A(0)};
+    Cplx<A> up[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) up[i] = Cplx<F>{F(0), F(0)};
-    Cplx<F> v[DEPTH][12];
+    for (int i = 0; i < 6; i++) up[i] = Cplx<A>{A(0), A(0)};
+    Cplx<A> v[DEPTH][12];
 #pragma unroll
     for (int j = 0; j < DEPTH - 1; j++)
-      if (j < a.nVec) load_spinor<F, ORDER, NT>(v[j], a.L[j], a.parity_offset, a.stride, parity, x_cb);
+      if (j < a.nVec) load_spinor<F, A, ORDER, NT>(v[j], a.L[j], a.parity_offset, a.stride, parity, x_cb);
     for (int n = 0; n < a.nVec; n += DEPTH) {
 #pragma unroll
       for (int j = 0; j < DEPTH; j++) {
         const int m = n + j;
         if (m < a.nVec) {
           const int pre = m + DEPTH - 1;
-          if (pre < a.nVec) load_spinor<F, ORDER, NT>(v[(j + DEPTH - 1) % DEPTH], a.L[pre], a.parity_offset, a.stride, parity, x_cb);
+          if (pre < a.nVec) load_spinor<F, A, ORDER, NT>(v[(j + DEPTH - 1) % DEPTH], a.L[pre], a.parity_offset, a.stride, parity, x_cb);
           accumulate_herm(diag, up, v[j], a.inv_sigma[m]);
         }
       }
@@ -143,21 +146,21 @@ __global__ __launch_bounds__(BLOCK) void loop_contract_kernel(ContractArgs<F> a)
     int p = 0;
 #pragma unroll
     for (int be = 0; be < 4; be++) {
-      acc[be * 4 + be] = Cplx<F>{diag[be], F(0)};
+      acc[be * 4 + be] = Cplx<A>{diag[be], A(0)};
 #pragma unroll
       for (int al = be + 1; al < 4; al++) {
         acc[be * 4 + al] = up[p];
-        acc[al * 4 + be] = Cplx<F>{up[p].re, -up[p].im};
+        acc[al * 4 + be] = Cplx<A>{up[p].re, -up[p].im};
         p++;
       }
     }
   } else {
-    Cplx<F> l[DEPTH][12], r[DEPTH][12];
+    Cplx<A> l[DEPTH][12], r[DEPTH][12];
 #pragma unroll
     for (int j = 0; j < DEPTH - 1; j++)
       if (j < a.nVec) {
-        load_spinor<F, ORDER, NT>(l[j], a.L[j], a.parity_offset, a.stride, parity, x_cb);
-        load_spinor<F, ORDER, NT>(r[j], a.R[j], a.parity_offset, a.stride, parity, x_cb);
+        load_spinor<F, A, ORDER, NT>(l[j], a.L[j], a.parity_offset, a.stride, parity, x_cb);
+        load_spinor<F, A, ORDER, NT>(r[j], a.R[j], a.parity_offset, a.stride, parity, x_cb);
       }
     for (int n = 0; n < a.nVec; n += DEPTH) {
 #pragma unroll
@@ -166,8 +169,8 @@ __global__ __launch_bounds__(BLOCK) void loop_contract_kernel(ContractArgs<F> a)
         if (m < a.nVec) {
           const int pre = m + DEPTH - 1;
           if (pre < a.nVec) {
-            load_spinor<F, ORDER, NT>(l[(j + DEPTH - 1) % DEPTH], a.L[pre], a.parity_offset, a.stride, parity, x_cb);
-            load_spinor<F, ORDER, NT>(r[(j + DEPTH - 1) % DEPTH], a.R[pre], a.parity_offset, a.stride, parity, x_cb);
+            load_spinor<F, A, ORDER, NT>(l[(j + DEPTH - 1) % DEPTH], a.L[pre], a.parity_offset, a.stride, parity, x_cb);
+            load_spinor<F, A, ORDER, NT>(r[(j + DEPTH - 1) % DEPTH], a.R[pre], a.parity_offset, a.stride, parity, x_cb);
           }
           accumulate_full(acc, l[j], r[j], a.inv_sigma[m]);
         }
@@ -197,69 +200,72 @@ static ContractTune contract_tune(bool same) {
   return t;
 }
 
-template <typename F, int ORDER, bool SAME, int BLOCK, int DEPTH>
-static void launch_variant(const ContractArgs<F> &a, int nt, hipStream_t stream) {
+template <typename F, typename A, int ORDER, bool SAME, int BLOCK, int DEPTH>
+static void launch_variant(const ContractArgs<A> &a, int nt, hipStream_t stream) {
   const int V = 2 * a.volumeCB;
   const dim3 grid((V + BLOCK - 1) / BLOCK), block(BLOCK);
-  if (nt) hipLaunchKernelGGL((loop_contract_kernel<F, ORDER, SAME, BLOCK, DEPTH, true>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((loop_contract_kernel<F, ORDER, SAME, BLOCK, DEPTH, false>), grid, block, 0, stream, a);
+  if (nt) hipLaunchKernelGGL((loop_contract_kernel<F, A, ORDER, SAME, BLOCK, DEPTH, true>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((loop_contract_kernel<F, A, ORDER, SAME, BLOCK, DEPTH, false>), grid, block, 0, stream, a);
 }
 
-template <typename F, int ORDER, bool SAME, int BLOCK>
-static void launch_depth(const ContractArgs<F> &a, const ContractTune &t, hipStream_t stream) {
-  if (t.depth == 1) launch_variant<F, ORDER, SAME, BLOCK, 1>(a, t.nt, stream);
-  else if (t.depth == 2 || !SAME) launch_variant<F, ORDER, SAME, BLOCK, 2>(a, t.nt, stream);
-  else launch_variant<F, ORDER, SAME, BLOCK, (SAME ? 3 : 2)>(a, t.nt, stream);
+template <typename F, typename A, int ORDER, bool SAME, int BLOCK>
+static void launch_depth(const ContractArgs<A> &a, const ContractTune &t, hipStream_t stream) {
+  if (t.depth == 1) launch_variant<F, A, ORDER, SAME, BLOCK, 1>(a, t.nt, stream);
+  else if (t.depth == 2 || !SAME) launch_variant<F, A, ORDER, SAME, BLOCK, 2>(a, t.nt, stream);
+  else launch_variant<F, A, ORDER, SAME, BLOCK, (SAME ? 3 : 2)>(a, t.nt, stream);
 }
 
-template <typename F, int ORDER, bool SAME>
-static void launch_block(const ContractArgs<F> &a, const ContractTune &t, hipStream_t stream) {
-  switch (t.block) {
-  case 64: launch_depth<F, ORDER, SAME, 64>(a, t, stream); break;
-  case 128: launch_depth<F, ORDER, SAME, 128>(a, t, stream); break;
-  case 512: launch_depth<F, ORDER, SAME, 512>(a, t, stream); break;
-  default: launch_depth<F, ORDER, SAME, 256>(a, t, stream); break;
+template <typename F, typename A, int ORDER, bool SAME>
+static void launch_block(const ContractArgs<A> &a, const ContractTune &t, hipStream_t stream) {
+  if constexpr (std::is_same<F, A>::value) {
+    switch (t.block) {
+    case 64: launch_depth<F, A, ORDER, SAME, 64>(a, t, stream); return;
+    case 128: launch_depth<F, A, ORDER, SAME, 128>(a, t, stream); return;
+    case 512: launch_depth<F, A, ORDER, SAME, 512>(a, t, stream); return;
+    default: break;
+    }
   }
+  launch_depth<F, A, ORDER, SAME, 256>(a, t, stream);  // the mixed mode is built for the default block size only
 }
 
-template <typename F, int ORDER>
+template <typename F, typename A, int ORDER>
 static int launch_contract(void *loop_d, const MugiqHipSpinorField *L, const MugiqHipSpinorField *R, const double *sigma,
                            int nVec, bool same, hipStream_t stream) {
   // device tables: [L pointers][R pointers][inv_sigma]
   const size_t ptr_bytes = sizeof(void *) * (size_t)nVec;
-  const size_t tab_bytes = 2 * ptr_bytes + sizeof(F) * (size_t)nVec;
+  const size_t tab_bytes = 2 * ptr_bytes + sizeof(A) * (size_t)nVec;
   std::vector<unsigned char> host(tab_bytes);
   const void **hl = reinterpret_cast<const void **>(host.data());
   const void **hr = reinterpret_cast<const void **>(host.data() + ptr_bytes);
-  F *hs = reinterpret_cast<F *>(host.data() + 2 * ptr_bytes);
+  A *hs = reinterpret_cast<A *>(host.data() + 2 * ptr_bytes);
   for (int n = 0; n < nVec; n++) {
     hl[n] = L[n].data;
     hr[n] = R[n].data;
     const F sg = static_cast<F>(sigma[n]);   // (Float) eVals_sigma[n]   lib/loop_mugiq.cpp:479
-    hs[n] = static_cast<F>(1.0 / sg);        // inv_sigma(1.0/sigma)     include/contract_util.cuh:132
+    hs[n] = static_cast<A>(1.0 / sg);        // inv_sigma(1.0/sigma)     include/contract_util.cuh:132
   }
   void *dev = nullptr;
   int st = upload_table(&dev, host.data(), tab_bytes, stream);
   if (st) return st;
 
-  ContractArgs<F> a;
-  a.loop = static_cast<Cplx<F> *>(loop_d);
+  ContractArgs<A> a;
+  a.loop = static_cast<Cplx<A> *>(loop_d);
   a.L = reinterpret_cast<const void *const *>(dev);
   a.R = reinterpret_cast<const void *const *>(static_cast<unsigned char *>(dev) + ptr_bytes);
-  a.inv_sigma = reinterpret_cast<const F *>(static_cast<unsigned char *>(dev) + 2 * ptr_bytes);
+  a.inv_sigma = reinterpret_cast<const A *>(static_cast<unsigned char *>(dev) + 2 * ptr_bytes);
   a.nVec = nVec;
   a.volumeCB = L[0].volumeCB;
   a.stride = L[0].stride;
   a.parity_offset = L[0].parity_offset;
   const ContractTune t = contract_tune(same);
-  if (same) launch_block<F, ORDER, true>(a, t, stream);
-  else launch_block<F, ORDER, false>(a, t, stream);
+  if (same) launch_block<F, A, ORDER, true>(a, t, stream);
+  else launch_block<F, A, ORDER, false>(a, t, stream);
   MUGIQ_CHECK_HIP(hipGetLastError());
   return MUGIQ_HIP_SUCCESS;
 }
 
-static int contract_dispatch(void *loop_d, const MugiqHipSpinorField *L, const MugiqHipSpinorField *R, const double *sigma,
-                             int nVec, void *stream, const char *who) {
+static int contract_dispatch(void *loop_d, int loopPrecision, const MugiqHipSpinorField *L, const MugiqHipSpinorField *R,
+                             const double *sigma, int nVec, void *stream, const char *who) {
   MUGIQ_REQUIRE(loop_d != nullptr, "%s: loopData_d is NULL", who);
   MUGIQ_REQUIRE(L != nullptr && R != nullptr && sigma != nullptr, "%s: NULL argument", who);
   MUGIQ_REQUIRE(nVec >= 1, "%s: nVec = %d must be >= 1", who, nVec);
@@ -276,10 +282,18 @@ static int contract_dispatch(void *loop_d, const MugiqHipSpinorField *L, const M
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int prec = L[0].precision, order = L[0].field_order;
-  if (prec == 8 && order == 2) return launch_contract<double, 2>(loop_d, L, R, sigma, nVec, same, s);
-  if (prec == 8 && order == 4) return launch_contract<double, 4>(loop_d, L, R, sigma, nVec, same, s);
-  if (prec == 4 && order == 2) return launch_contract<float, 2>(loop_d, L, R, sigma, nVec, same, s);
-  return launch_contract<float, 4>(loop_d, L, R, sigma, nVec, same, s);
+  if (loopPrecision == 0) loopPrecision = prec;
+  MUGIQ_REQUIRE(loopPrecision == prec || (loopPrecision == 8 && prec == 4),
+                "%s: loop precision %d with field precision %d is not supported (same precision, or fp64 loops over fp32 fields)",
+                who, loopPrecision, prec);
+  if (prec == 8 && order == 2) return launch_contract<double, double, 2>(loop_d, L, R, sigma, nVec, same, s);
+  if (prec == 8 && order == 4) return launch_contract<double, double, 4>(loop_d, L, R, sigma, nVec, same, s);
+  if (loopPrecision == 8) {
+    if (order == 2) return launch_contract<float, double, 2>(loop_d, L, R, sigma, nVec, same, s);
+    return launch_contract<float, double, 4>(loop_d, L, R, sigma, nVec, same, s);
+  }
+  if (order == 2) return launch_contract<float, float, 2>(loop_d, L, R, sigma, nVec, same, s);
+  return launch_contract<float, float, 4>(loop_d, L, R, sigma, nVec, same, s);
 }
 
 }  // namespace mugiq
@@ -288,13 +302,20 @@ extern "C" {
 
 int mugiq_hip_perform_loop_contraction(void *loopData_d, const MugiqHipSpinorField *eVecL, const MugiqHipSpinorField *eVecR,
                                        double sigma, void *stream) {
-  return mugiq::contract_dispatch(loopData_d, eVecL, eVecR, &sigma, 1, stream, "performLoopContraction");
+  return mugiq::contract_dispatch(loopData_d, 0, eVecL, eVecR, &sigma, 1, stream, "performLoopContraction");
 }
 
 int mugiq_hip_perform_loop_contraction_batched(void *loopData_d, const MugiqHipSpinorField *eVecL_h,
                                                const MugiqHipSpinorField *eVecR_h, const double *sigma_h, int nVec,
                                                void *stream) {
-  return mugiq::contract_dispatch(loopData_d, eVecL_h, eVecR_h, sigma_h, nVec, stream, "performLoopContractionBatched");
+  return mugiq::contract_dispatch(loopData_d, 0, eVecL_h, eVecR_h, sigma_h, nVec, stream, "performLoopContractionBatched");
+}
+
+int mugiq_hip_perform_loop_contraction_batched_mixed(void *loopData_d, int loopPrecision, const MugiqHipSpinorField *eVecL_h,
+                                                     const MugiqHipSpinorField *eVecR_h, const double *sigma_h, int nVec,
+                                                     void *stream) {
+  return mugiq::contract_dispatch(loopData_d, loopPrecision, eVecL_h, eVecR_h, sigma_h, nVec, stream,
+                                  "performLoopContractionBatchedMixed");
 }
 
 }  // extern "C"

@@ -22,11 +22,12 @@ namespace mugiq {
 
 constexpr int kFusedMaxSlots = 4;
 
-template <typename F> struct FusedArgs {
-  Cplx<F> *loop;            // first slot handled by this launch
+// F = storage type of eigenvectors / links, A = arithmetic and loop-buffer type (F, or double over float storage)
+template <typename F, typename A> struct FusedArgs {
+  Cplx<A> *loop;            // first slot handled by this launch
   int64_t slot_stride;      // complex elements between consecutive slots (16*V)
   const void *const *L;     // device table of eigenvector bodies
-  const F *inv_sigma;       // device [nVec]
+  const A *inv_sigma;       // device [nVec]
   int nVec;
   int X[4];
   int volumeCB;
@@ -41,10 +42,13 @@ template <typename F> struct FusedArgs {
   int faceCB;
 };
 
-template <typename F, int ORDER> __device__ inline void load_lane(Cplx<F> v[12], const Cplx<F> *p, int64_t stride, int64_t idx) {
+template <typename F, typename A, int ORDER> __device__ inline void load_lane(Cplx<A> v[12], const Cplx<F> *p, int64_t stride, int64_t idx) {
   if constexpr (ORDER == 2) {
 #pragma unroll
-    for (int k = 0; k < 12; k++) v[k] = p[k * stride + idx];
+    for (int k = 0; k < 12; k++) {
+      const Cplx<F> t = p[k * stride + idx];
+      v[k] = Cplx<A>{(A)t.re, (A)t.im};
+    }
   } else {
     struct alignas(4 * sizeof(F)) Pair {
       Cplx<F> a, b;
@@ -53,14 +57,14 @@ template <typename F, int ORDER> __device__ inline void load_lane(Cplx<F> v[12],
 #pragma unroll
     for (int j = 0; j < 6; j++) {
       Pair t = q[j * stride + idx];
-      v[2 * j] = t.a;
-      v[2 * j + 1] = t.b;
+      v[2 * j] = Cplx<A>{(A)t.a.re, (A)t.a.im};
+      v[2 * j + 1] = Cplx<A>{(A)t.b.re, (A)t.b.im};
     }
   }
 }
 
-template <typename F, int ORDER, int DIR, int SIGN>
-__global__ __launch_bounds__(64 * kFusedMaxSlots) void fused_displaced_contract_kernel(FusedArgs<F> a) {
+template <typename F, typename A, int ORDER, int DIR, int SIGN>
+__global__ __launch_bounds__(64 * kFusedMaxSlots) void fused_displaced_contract_kernel(FusedArgs<F, A> a) {
   const int V = 2 * a.volumeCB;
   const int site = blockIdx.x * 64 + threadIdx.x;
   const int slot = threadIdx.y;
@@ -101,36 +105,39 @@ __global__ __launch_bounds__(64 * kFusedMaxSlots) void fused_displaced_contract_
   }
 
   // ---- W_k(x): 3x3 from the first 9 planes of E_k -----------------------------------------------------------
-  Cplx<F> W[9];  // W[i*3+j]
+  Cplx<A> W[9];  // W[i*3+j]
   {
     const Cplx<F> *e = reinterpret_cast<const Cplx<F> *>(a.E[slot]) + (int64_t)pty * 12 * a.volumeCB + x_cb;
 #pragma unroll
     for (int j = 0; j < 3; j++)
 #pragma unroll
-      for (int i = 0; i < 3; i++) W[i * 3 + j] = e[(int64_t)(j * 3 + i) * a.volumeCB];
+      for (int i = 0; i < 3; i++) {
+        const Cplx<F> t = e[(int64_t)(j * 3 + i) * a.volumeCB];
+        W[i * 3 + j] = Cplx<A>{(A)t.re, (A)t.im};
+      }
   }
 
-  Cplx<F> acc[16];
+  Cplx<A> acc[16];
 #pragma unroll
-  for (int i = 0; i < 16; i++) acc[i] = Cplx<F>{F(0), F(0)};
+  for (int i = 0; i < 16; i++) acc[i] = Cplx<A>{A(0), A(0)};
 
   const Cplx<F> *ghostBase = reinterpret_cast<const Cplx<F> *>(a.ghost);
   for (int n = 0; n < a.nVec; n++) {
     const Cplx<F> *body = reinterpret_cast<const Cplx<F> *>(a.L[n]);
-    Cplx<F> l[12], psi[12];
-    load_lane<F, ORDER>(l, body + (int64_t)pty * a.parity_offset, a.stride, x_cb);
+    Cplx<A> l[12], psi[12];
+    load_lane<F, A, ORDER>(l, body + (int64_t)pty * a.parity_offset, a.stride, x_cb);
     const Cplx<F> *src = inGhost ? ghostBase + (int64_t)n * a.ghost_vec_stride : body;
-    load_lane<F, ORDER>(psi, src + nOff, nStride, nIdx);
-    const F s = a.inv_sigma[n];
-    Cplx<F> r[12];
+    load_lane<F, A, ORDER>(psi, src + nOff, nStride, nIdx);
+    const A s = a.inv_sigma[n];
+    Cplx<A> r[12];
 #pragma unroll
     for (int sp = 0; sp < 4; sp++)
 #pragma unroll
       for (int i = 0; i < 3; i++) {
-        Cplx<F> t{F(0), F(0)};
+        Cplx<A> t{A(0), A(0)};
 #pragma unroll
         for (int j = 0; j < 3; j++) cmadd(t, W[i * 3 + j], psi[sp * 3 + j]);
-        r[sp * 3 + i] = Cplx<F>{s * t.re, s * t.im};
+        r[sp * 3 + i] = Cplx<A>{s * t.re, s * t.im};
       }
 #pragma unroll
     for (int be = 0; be < 4; be++)
@@ -140,14 +147,14 @@ __global__ __launch_bounds__(64 * kFusedMaxSlots) void fused_displaced_contract_
         for (int c = 0; c < 3; c++) cmadd_conj(acc[be * 4 + al], l[be * 3 + c], r[al * 3 + c]);
   }
 
-  Cplx<F> *loop = a.loop + (int64_t)slot * a.slot_stride;
+  Cplx<A> *loop = a.loop + (int64_t)slot * a.slot_stride;
 #pragma unroll
   for (int iG = 0; iG < 16; iG++) {
-    Cplx<F> t{F(0), F(0)};
+    Cplx<A> t{A(0), A(0)};
 #pragma unroll
     for (int s2 = 0; s2 < 4; s2++) add_phase(t, kGammaPhase[iG][s2], acc[s2 * 4 + kGammaColumn[iG][s2]]);
-    Cplx<F> *out = loop + (int64_t)V * iG + site;
-    Cplx<F> o = *out;
+    Cplx<A> *out = loop + (int64_t)V * iG + site;
+    Cplx<A> o = *out;
     o.re += t.re;
     o.im += t.im;
     *out = o;
@@ -193,13 +200,13 @@ __global__ __launch_bounds__(256) void pack_layers_kernel(PackLayersArgs<F> g) {
   dst.store(v, pty, idx);
 }
 
-template <typename F, int ORDER>
-static int launch_fused(const FusedArgs<F> &a, int dir, int sign, hipStream_t stream) {
+template <typename F, typename A, int ORDER>
+static int launch_fused(const FusedArgs<F, A> &a, int dir, int sign, hipStream_t stream) {
   const int V = 2 * a.volumeCB;
   const dim3 grid((V + 63) / 64), block(64, a.nslot);
 #define MUGIQ_FUSED_CASE(D, S)                                                                              \
   case (D)*2 + (S):                                                                                         \
-    hipLaunchKernelGGL((fused_displaced_contract_kernel<F, ORDER, D, S>), grid, block, 0, stream, a);       \
+    hipLaunchKernelGGL((fused_displaced_contract_kernel<F, A, ORDER, D, S>), grid, block, 0, stream, a);       \
     break;
   switch (dir * 2 + sign) {
     MUGIQ_FUSED_CASE(0, 0) MUGIQ_FUSED_CASE(0, 1) MUGIQ_FUSED_CASE(1, 0) MUGIQ_FUSED_CASE(1, 1)
@@ -210,26 +217,26 @@ static int launch_fused(const FusedArgs<F> &a, int dir, int sign, hipStream_t st
   return MUGIQ_HIP_SUCCESS;
 }
 
-template <typename F, int ORDER>
+template <typename F, typename A, int ORDER>
 static int fused_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d,
                        const int *kvals, int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers,
                        hipStream_t stream) {
   const size_t ptr_bytes = sizeof(void *) * (size_t)nVec;
-  std::vector<unsigned char> host(ptr_bytes + sizeof(F) * (size_t)nVec);
+  std::vector<unsigned char> host(ptr_bytes + sizeof(A) * (size_t)nVec);
   const void **hl = reinterpret_cast<const void **>(host.data());
-  F *hs = reinterpret_cast<F *>(host.data() + ptr_bytes);
+  A *hs = reinterpret_cast<A *>(host.data() + ptr_bytes);
   for (int n = 0; n < nVec; n++) {
     hl[n] = ev[n].data;
     const F sg = static_cast<F>(sigma[n]);
-    hs[n] = static_cast<F>(1.0 / sg);
+    hs[n] = static_cast<A>(1.0 / sg);
   }
   void *dev = nullptr;
   int st = upload_table(&dev, host.data(), host.size(), stream);
   if (st) return st;
-  FusedArgs<F> a;
+  FusedArgs<F, A> a;
   a.slot_stride = (int64_t)16 * 2 * ev[0].volumeCB;
   a.L = reinterpret_cast<const void *const *>(dev);
-  a.inv_sigma = reinterpret_cast<const F *>(static_cast<unsigned char *>(dev) + ptr_bytes);
+  a.inv_sigma = reinterpret_cast<const A *>(static_cast<unsigned char *>(dev) + ptr_bytes);
   a.nVec = nVec;
   for (int d = 0; d < 4; d++) a.X[d] = ev[0].X[d];
   a.volumeCB = ev[0].volumeCB;
@@ -241,12 +248,12 @@ static int fused_entry(void *loop_d, const MugiqHipSpinorField *ev, const double
   a.ghost_vec_stride = (int64_t)layers * 24 * a.faceCB;
   for (int k0 = 0; k0 < nK; k0 += kFusedMaxSlots) {
     a.nslot = (nK - k0 < kFusedMaxSlots) ? nK - k0 : kFusedMaxSlots;
-    a.loop = static_cast<Cplx<F> *>(loop_d) + (int64_t)k0 * a.slot_stride;
+    a.loop = static_cast<Cplx<A> *>(loop_d) + (int64_t)k0 * a.slot_stride;
     for (int s = 0; s < kFusedMaxSlots; s++) {
       a.E[s] = static_cast<const F *>(E_d[k0 + (s < a.nslot ? s : 0)]);
       a.k[s] = kvals[k0 + (s < a.nslot ? s : 0)];
     }
-    st = launch_fused<F, ORDER>(a, dir, sign, stream);
+    st = launch_fused<F, A, ORDER>(a, dir, sign, stream);
     if (st) return st;
   }
   return MUGIQ_HIP_SUCCESS;
@@ -302,10 +309,10 @@ int mugiq_hip_pack_face_layers(void *faces_d, const MugiqHipSpinorField *eVecs_h
   return pack_layers<float, 4>(faces_d, eVecs_h, nVec, dim, high, layers, s);
 }
 
-int mugiq_hip_displaced_loop_contraction_fused(void *loopData_d, const MugiqHipSpinorField *eVecs_h, const double *sigma_h,
-                                               int nVec, const void *const *pathLinkFields_h, const int *kValues_h, int nK,
-                                               int dispDir, int dispSign, const int commDim[4], const void *ghostLayers_d,
-                                               int layers, void *stream) {
+int mugiq_hip_displaced_loop_contraction_fused_mixed(void *loopData_d, int loopPrecision, const MugiqHipSpinorField *eVecs_h,
+                                                     const double *sigma_h, int nVec, const void *const *pathLinkFields_h,
+                                                     const int *kValues_h, int nK, int dispDir, int dispSign,
+                                                     const int commDim[4], const void *ghostLayers_d, int layers, void *stream) {
   const char *who = "mugiq_hip_displaced_loop_contraction_fused";
   MUGIQ_REQUIRE(loopData_d && eVecs_h && sigma_h && pathLinkFields_h && kValues_h, "%s: NULL argument", who);
   MUGIQ_REQUIRE(nVec >= 1 && nK >= 1, "%s: nVec = %d, nK = %d must be >= 1", who, nVec, nK);
@@ -331,17 +338,27 @@ int mugiq_hip_displaced_loop_contraction_fused(void *loopData_d, const MugiqHipS
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int p = eVecs_h[0].precision, o = eVecs_h[0].field_order;
-  if (p == 8 && o == 2)
-    return fused_entry<double, 2>(loopData_d, eVecs_h, sigma_h, nVec, pathLinkFields_h, kValues_h, nK, dispDir, dispSign, part,
-                                  ghostLayers_d, layers, s);
-  if (p == 8 && o == 4)
-    return fused_entry<double, 4>(loopData_d, eVecs_h, sigma_h, nVec, pathLinkFields_h, kValues_h, nK, dispDir, dispSign, part,
-                                  ghostLayers_d, layers, s);
-  if (p == 4 && o == 2)
-    return fused_entry<float, 2>(loopData_d, eVecs_h, sigma_h, nVec, pathLinkFields_h, kValues_h, nK, dispDir, dispSign, part,
-                                 ghostLayers_d, layers, s);
-  return fused_entry<float, 4>(loopData_d, eVecs_h, sigma_h, nVec, pathLinkFields_h, kValues_h, nK, dispDir, dispSign, part,
-                               ghostLayers_d, layers, s);
+  if (loopPrecision == 0) loopPrecision = p;
+  MUGIQ_REQUIRE(loopPrecision == p || (loopPrecision == 8 && p == 4),
+                "%s: loop precision %d with field precision %d is not supported", who, loopPrecision, p);
+#define MUGIQ_FUSED_GO(F, A, O)                                                                                                 \
+  return fused_entry<F, A, O>(loopData_d, eVecs_h, sigma_h, nVec, pathLinkFields_h, kValues_h, nK, dispDir, dispSign, part,   \
+                              ghostLayers_d, layers, s)
+  if (p == 8 && o == 2) MUGIQ_FUSED_GO(double, double, 2);
+  if (p == 8 && o == 4) MUGIQ_FUSED_GO(double, double, 4);
+  if (loopPrecision == 8 && o == 2) MUGIQ_FUSED_GO(float, double, 2);
+  if (loopPrecision == 8) MUGIQ_FUSED_GO(float, double, 4);
+  if (o == 2) MUGIQ_FUSED_GO(float, float, 2);
+  MUGIQ_FUSED_GO(float, float, 4);
+#undef MUGIQ_FUSED_GO
+}
+
+int mugiq_hip_displaced_loop_contraction_fused(void *loopData_d, const MugiqHipSpinorField *eVecs_h, const double *sigma_h,
+                                               int nVec, const void *const *pathLinkFields_h, const int *kValues_h, int nK,
+                                               int dispDir, int dispSign, const int commDim[4], const void *ghostLayers_d,
+                                               int layers, void *stream) {
+  return mugiq_hip_displaced_loop_contraction_fused_mixed(loopData_d, 0, eVecs_h, sigma_h, nVec, pathLinkFields_h, kValues_h, nK,
+                                                          dispDir, dispSign, commDim, ghostLayers_d, layers, stream);
 }
 
 }  // extern "C"

@@ -55,6 +55,7 @@ struct MugiqHipLoop_s {
   std::vector<MugiqHipSpinorField> eVecs;
   std::vector<double> sigma;
   int nEv = 0, precision = 8, order = 2;
+  int loopPrecision = 8;  // precision of the loop buffers / FT (= precision, or 8 over fp32 fields: mixed mode)
   MugiqHipGaugeField gauge;
   bool haveGauge = false;
   MugiqHipComm comm;
@@ -70,7 +71,8 @@ struct MugiqHipLoop_s {
   // ---- displacement scratch (Displace::auxDispVec and friends)
   std::vector<void *> scratch;  // device allocations freed in the destructor
 
-  size_t cplxBytes() const { return 2 * (size_t)precision; }
+  size_t cplxBytes() const { return 2 * (size_t)precision; }      // eigenvector / link storage
+  size_t loopBytes() const { return 2 * (size_t)loopPrecision; }  // loop buffers, phases, momentum projection
 };
 
 namespace mugiq {
@@ -129,7 +131,7 @@ static int entry_basic(MugiqHipLoop *lp, int id, void *slot0) {
     if ((st = dev_alloc(lp, &recv_d, fb, false))) return st;
     lp->scratch.push_back(recv_d);
   }
-  const size_t slotBytes = (size_t)lp->nElemPosLocPerLoop * lp->cplxBytes();
+  const size_t slotBytes = (size_t)lp->nElemPosLocPerLoop * lp->loopBytes();
   for (int n = 0; n < lp->nEv; n++) {  // lib/loop_mugiq.cpp:478
     MugiqHipSpinorField cur = lp->eVecs[n];
     int dispCount = 0;
@@ -141,7 +143,9 @@ static int entry_basic(MugiqHipLoop *lp, int id, void *slot0) {
       cur = *dst;
       if (idisp >= lp->dispStart[id] && idisp <= lp->dispStop[id]) {  // :491-496
         void *slot = static_cast<char *>(slot0) + slotBytes * dispCount;
-        if ((st = mugiq_hip_perform_loop_contraction(slot, &lp->eVecs[n], &cur, lp->sigma[n], lp->stream))) return st;
+        if ((st = mugiq_hip_perform_loop_contraction_batched_mixed(slot, lp->loopPrecision, &lp->eVecs[n], &cur, &lp->sigma[n], 1,
+                                                                   lp->stream)))
+          return st;
         dispCount++;
       }
     }
@@ -218,8 +222,9 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
       st = lp->comm.sendrecv(lp->comm.ctx, gsend, grecv, perVec * nv, dir, high ? +1 : -1, lp->stream);
       if (st) return set_error(MUGIQ_HIP_ERROR_HIP, "halo sendrecv callback failed with status %d", st);
     }
-    if ((st = mugiq_hip_displaced_loop_contraction_fused(slot0, &lp->eVecs[n0], &lp->sigma[n0], nv, links.data(), kv.data(),
-                                                         (int)kv.size(), dir, sign, lp->commDim, grecv, stop, lp->stream)))
+    if ((st = mugiq_hip_displaced_loop_contraction_fused_mixed(slot0, lp->loopPrecision, &lp->eVecs[n0], &lp->sigma[n0], nv,
+                                                               links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
+                                                               grecv, stop, lp->stream)))
       return st;
   }
   return MUGIQ_HIP_SUCCESS;
@@ -235,21 +240,21 @@ static int momentum_projection(MugiqHipLoop *lp) {
   if (lp->momProjDone) return set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "performMomentumProjection: Not supposed to be called more than once!!");
   int st;
   if ((st = mugiq_hip_convert_idx_order_map_gamma(lp->dataPosMP_d, lp->dataPos_d, lp->nData, lp->nLoop, 2, lp->volumeCB,
-                                                  lp->localL, lp->precision, lp->stream)))  // :343-344
+                                                  lp->localL, lp->loopPrecision, lp->stream)))  // :343-344
     return st;
   if ((st = mugiq_hip_momentum_projection(lp->dataMom_d, lp->dataPosMP_d, lp->phaseMatrix_d, lp->locT, lp->nData, lp->locV3,
-                                          lp->Nmom, lp->precision, nullptr, 0, lp->stream)))  // :363-378
+                                          lp->Nmom, lp->loopPrecision, nullptr, 0, lp->stream)))  // :363-378
     return st;
-  const size_t locBytes = (size_t)lp->nElemMomLoc * lp->cplxBytes();
+  const size_t locBytes = (size_t)lp->nElemMomLoc * lp->loopBytes();
   MUGIQ_CHECK_HIP(hipMemcpyAsync(lp->dataMom_h, lp->dataMom_d, locBytes, hipMemcpyDeviceToHost, lp->stream));  // :386
   MUGIQ_CHECK_HIP(hipStreamSynchronize(lp->stream));
   if (lp->haveComm && lp->comm.size > 1) {
     const size_t nReal = 2 * (size_t)lp->nElemMomLoc;
-    if ((st = lp->comm.reduce_space(lp->comm.ctx, lp->dataMom_h, lp->dataMom, nReal, lp->precision)))  // :406
+    if ((st = lp->comm.reduce_space(lp->comm.ctx, lp->dataMom_h, lp->dataMom, nReal, lp->loopPrecision)))  // :406
       return set_error(MUGIQ_HIP_ERROR_HIP, "reduce_space callback failed with status %d", st);
-    if ((st = lp->comm.gather_time(lp->comm.ctx, lp->dataMom, lp->dataMom_bcast, nReal, lp->precision)))  // :420-422
+    if ((st = lp->comm.gather_time(lp->comm.ctx, lp->dataMom, lp->dataMom_bcast, nReal, lp->loopPrecision)))  // :420-422
       return set_error(MUGIQ_HIP_ERROR_HIP, "gather_time callback failed with status %d", st);
-    if ((st = lp->comm.bcast(lp->comm.ctx, lp->dataMom_bcast, 2 * (size_t)lp->nElemMomTot, lp->precision)))  // :424
+    if ((st = lp->comm.bcast(lp->comm.ctx, lp->dataMom_bcast, 2 * (size_t)lp->nElemMomTot, lp->loopPrecision)))  // :424
       return set_error(MUGIQ_HIP_ERROR_HIP, "bcast callback failed with status %d", st);
   } else {
     memcpy(lp->dataMom, lp->dataMom_h, locBytes);
@@ -335,6 +340,12 @@ int mugiq_hip_loop_create(MugiqHipLoop **out, const MugiqHipLoopParam *p, const 
   lp->sigma.assign(eVals_sigma_h, eVals_sigma_h + nEv);
   lp->nEv = nEv;
   lp->precision = eVecs_h[0].precision;
+  lp->loopPrecision = p->loopPrecision ? p->loopPrecision : lp->precision;
+  if (!(lp->loopPrecision == lp->precision || (lp->loopPrecision == 8 && lp->precision == 4))) {
+    set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "%s: loopPrecision %d with eigenvector precision %d is not supported", who,
+              lp->loopPrecision, lp->precision);
+    return fail(MUGIQ_HIP_ERROR_INVALID_ARGUMENT);
+  }
   lp->order = eVecs_h[0].field_order;
   lp->volumeCB = eVecs_h[0].volumeCB;
   if (comm) {
@@ -436,7 +447,7 @@ int mugiq_hip_loop_create(MugiqHipLoop **out, const MugiqHipLoopParam *p, const 
   lp->nElemMomLoc = lp->nElemMomLocPerLoop * lp->nLoop;
   lp->nElemPosLoc = lp->nElemPosLocPerLoop * lp->nLoop;
   lp->nElemPhMat = (long long)lp->Nmom * lp->locV3;
-  const size_t cb = lp->cplxBytes();
+  const size_t cb = lp->loopBytes();
   if ((st = dev_alloc(lp, &lp->dataPos_d, (size_t)lp->nElemPosLoc * cb, true))) return fail(st);
   if (lp->doMomProj) {
     lp->dataMom_bcast = calloc((size_t)lp->nElemMomTot, cb);
@@ -453,12 +464,12 @@ int mugiq_hip_loop_create(MugiqHipLoop **out, const MugiqHipLoopParam *p, const 
   // copyGammaToConstMem :162-167, createPhaseMatrix :171-178
   if ((st = mugiq_hip_copy_gamma_coeff_to_symbol(lp->precision))) return fail(st);
   if (lp->doMomProj) {
-    if ((st = mugiq_hip_copy_gamma_map_to_symbol(lp->precision))) return fail(st);
+    if ((st = mugiq_hip_copy_gamma_map_to_symbol(lp->loopPrecision))) return fail(st);
     int cc[4] = {0, 0, 0, 0};
     if (lp->haveComm)
       for (int d = 0; d < 4; d++) cc[d] = lp->comm.coord[d];
     if ((st = mugiq_hip_create_phase_matrix(lp->phaseMatrix_d, lp->momMatrix.data(), lp->locV3, lp->Nmom, lp->FTSign, lp->localL,
-                                            lp->totalL, cc, lp->precision, lp->stream)))
+                                            lp->totalL, cc, lp->loopPrecision, lp->stream)))
       return fail(st);
   }
   *out = lp;
@@ -468,7 +479,7 @@ int mugiq_hip_loop_create(MugiqHipLoop **out, const MugiqHipLoopParam *p, const 
 int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
   MUGIQ_REQUIRE(lp != nullptr, "computeCoarseLoop: NULL loop handle");
   int st = MUGIQ_HIP_SUCCESS;
-  const size_t cb = lp->cplxBytes();
+  const size_t cb = lp->loopBytes();
   const bool basic = lp->calcType == MUGIQ_HIP_LOOP_CALC_TYPE_BASIC_KERNEL;
   for (int id = -1; id < lp->nDispEntries; id++) {  // lib/loop_mugiq.cpp:455
     long long bufOffset;
@@ -485,10 +496,11 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
     if (id == -1) {
       if (basic) {
         for (int n = 0; n < lp->nEv && !st; n++)  // :501-502
-          st = mugiq_hip_perform_loop_contraction(slot0, &lp->eVecs[n], &lp->eVecs[n], lp->sigma[n], lp->stream);
+          st = mugiq_hip_perform_loop_contraction_batched_mixed(slot0, lp->loopPrecision, &lp->eVecs[n], &lp->eVecs[n], &lp->sigma[n], 1,
+                                                                lp->stream);
       } else {
-        st = mugiq_hip_perform_loop_contraction_batched(slot0, lp->eVecs.data(), lp->eVecs.data(), lp->sigma.data(), lp->nEv,
-                                                        lp->stream);
+        st = mugiq_hip_perform_loop_contraction_batched_mixed(slot0, lp->loopPrecision, lp->eVecs.data(), lp->eVecs.data(),
+                                                              lp->sigma.data(), lp->nEv, lp->stream);
       }
     } else {
       st = basic ? entry_basic(lp, id, slot0) : entry_fused(lp, id, slot0);
@@ -512,6 +524,7 @@ int mugiq_hip_loop_get_info(const MugiqHipLoop *lp, MugiqHipLoopInfo *info) {
   info->nData = lp->nData;
   info->Nmom = lp->Nmom;
   info->precision = lp->precision;
+  info->loopPrecision = lp->loopPrecision;
   info->field_order = lp->order;
   for (int d = 0; d < 4; d++) {
     info->localL[d] = lp->localL[d];
@@ -548,8 +561,8 @@ const void *mugiq_hip_loop_data_pos_d(const MugiqHipLoop *lp) { return lp ? lp->
 
 const void *mugiq_hip_loop_data_pos_h(MugiqHipLoop *lp) {
   if (!lp) return nullptr;
-  const size_t bytes = (size_t)lp->nElemPosLoc * lp->cplxBytes();
-  if (!lp->dataPos) lp->dataPos = calloc((size_t)lp->nElemPosLoc, lp->cplxBytes());  // lib/loop_mugiq.cpp:116
+  const size_t bytes = (size_t)lp->nElemPosLoc * lp->loopBytes();
+  if (!lp->dataPos) lp->dataPos = calloc((size_t)lp->nElemPosLoc, lp->loopBytes());  // lib/loop_mugiq.cpp:116
   if (!lp->dataPos) return nullptr;
   if (!lp->dataPosCopied) {
     if (hipMemcpy(lp->dataPos, lp->dataPos_d, bytes, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;  // :512
@@ -593,7 +606,7 @@ int mugiq_hip_loop_write_hdf5(MugiqHipLoop *lp) {
     }
     MUGIQ_REQUIRE(!lp->fnameMom.empty(), "Got --loop-write-mom-space yes but no filename was given. Set option --loop-mom-space-filename");
     if (!lp->haveComm || lp->comm.rank == 0) {  // dataMom_bcast is replicated; one writer produces the identical file
-      int st = write_loops_hdf5_mom(lp->fnameMom.c_str(), lp->dataMom_bcast, lp->precision, lp->Nmom, lp->momMatrix.data(),
+      int st = write_loops_hdf5_mom(lp->fnameMom.c_str(), lp->dataMom_bcast, lp->loopPrecision, lp->Nmom, lp->momMatrix.data(),
                                     lp->nDispEntries, lp->dispString, lp->dispStart, lp->dispStop, lp->nLoop, lp->locT, lp->totT);
       if (st) return st;
     }

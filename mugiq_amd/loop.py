@@ -21,12 +21,12 @@ class _CLoopParam(ctypes.Structure):
                 ("disp_entry", ctypes.POINTER(ctypes.c_char_p)), ("disp_str", ctypes.POINTER(ctypes.c_char_p)),
                 ("disp_start", ctypes.POINTER(ctypes.c_int)), ("disp_stop", ctypes.POINTER(ctypes.c_int)),
                 ("fname_mom_h5", ctypes.c_char_p), ("fname_pos_h5", ctypes.c_char_p),
-                ("gauge", ctypes.POINTER(_lib.GaugeDesc))]
+                ("gauge", ctypes.POINTER(_lib.GaugeDesc)), ("loopPrecision", ctypes.c_int)]
 
 
 class _CLoopInfo(ctypes.Structure):
     _fields_ = [("nDispEntries", ctypes.c_int), ("nLoop", ctypes.c_int), ("nData", ctypes.c_int), ("Nmom", ctypes.c_int),
-                ("precision", ctypes.c_int), ("field_order", ctypes.c_int),
+                ("precision", ctypes.c_int), ("field_order", ctypes.c_int), ("loopPrecision", ctypes.c_int),
                 ("localL", ctypes.c_int * 4), ("totalL", ctypes.c_int * 4), ("locT", ctypes.c_int), ("totT", ctypes.c_int),
                 ("locV4", ctypes.c_longlong), ("locV3", ctypes.c_longlong), ("totV3", ctypes.c_longlong),
                 ("nElemPosLocPerLoop", ctypes.c_longlong), ("nElemMomLocPerLoop", ctypes.c_longlong),
@@ -53,6 +53,7 @@ class MugiqLoopParam:
     disp_start: List[int] = field(default_factory=list)
     disp_stop: List[int] = field(default_factory=list)
     gauge: Optional[GaugeField] = None
+    loopPrecision: int = 0          # not in the reference: 8 over fp32 eigenvectors = mixed precision (configs[3])
 
     def set_displace_entry_string(self, s):
         """--displace-entry-string "+z:1,8;-x:3" (tests/loop.cpp:656-705)"""
@@ -140,6 +141,7 @@ class Loop_Mugiq:
             g = loopParams.gauge.desc()
             self._keep += [g, loopParams.gauge]
             p.gauge = ctypes.pointer(g)
+        p.loopPrecision = int(loopParams.loopPrecision)
         self.eVecs = list(eVecs)
         descs = desc_array(self.eVecs)
         sg = (ctypes.c_double * len(self.eVecs))(*[float(s) for s in eVals_sigma])
@@ -152,7 +154,7 @@ class Loop_Mugiq:
         info = _CLoopInfo()
         _lib.check(lib.mugiq_hip_loop_get_info(self._handle, ctypes.byref(info)))
         self.info = info
-        for k in ("nDispEntries", "nLoop", "nData", "Nmom", "precision", "locT", "totT", "locV4", "locV3", "totV3",
+        for k in ("nDispEntries", "nLoop", "nData", "Nmom", "precision", "loopPrecision", "locT", "totT", "locV4", "locV3", "totV3",
                   "nElemPosLocPerLoop", "nElemMomLocPerLoop", "nElemMomTotPerLoop", "nElemPosLoc", "nElemMomLoc", "nElemMomTot"):
             setattr(self, k, getattr(info, k))
         self.localL, self.totalL = tuple(info.localL), tuple(info.totalL)
@@ -172,8 +174,8 @@ class Loop_Mugiq:
     def dataPos_d(self):
         """device view [nLoop*16*V] complex of the position-space loop buffer"""
         ptr = _lib.load().mugiq_hip_loop_data_pos_d(self._handle)
-        nbytes = self.nElemPosLoc * 2 * self.precision
-        return device_bytes(ptr, nbytes, self.device).view(torch.complex128 if self.precision == 8 else torch.complex64)
+        nbytes = self.nElemPosLoc * 2 * self.loopPrecision
+        return device_bytes(ptr, nbytes, self.device).view(torch.complex128 if self.loopPrecision == 8 else torch.complex64)
 
     @property
     def dataMom_bcast(self):
@@ -181,9 +183,9 @@ class Loop_Mugiq:
         ptr = _lib.load().mugiq_hip_loop_data_mom_bcast_h(self._handle)
         if not ptr:
             return None
-        ct = ctypes.c_double if self.precision == 8 else ctypes.c_float
+        ct = ctypes.c_double if self.loopPrecision == 8 else ctypes.c_float
         a = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ct)), shape=(2 * self.nElemMomTot,))
-        return a.view(np.complex128 if self.precision == 8 else np.complex64).copy()
+        return a.view(np.complex128 if self.loopPrecision == 8 else np.complex64).copy()
 
     def dataMom_global(self):
         """dataMom_bcast rearranged to [Nmom][nLoop][16][totT]"""

@@ -68,14 +68,16 @@ def performLoopContraction(loopData_d, eVecL, eVecR, sigma):
 
 
 def performLoopContractionBatched(loopData_d, eVecsL, eVecsR, sigmas):
-    """The eigenvector loop of Loop_Mugiq::computeCoarseLoop (lib/loop_mugiq.cpp:478-503) in one launch."""
+    """The eigenvector loop of Loop_Mugiq::computeCoarseLoop (lib/loop_mugiq.cpp:478-503) in one launch.
+    A complex128 loop buffer over fp32 eigenvectors selects the mixed-precision mode (fp64 accumulation)."""
     n = len(eVecsL)
     assert len(eVecsR) == n and len(sigmas) == n and n >= 1
-    assert _prec_of(loopData_d) == eVecsL[0].precision and loopData_d.numel() >= N_GAMMA * 2 * eVecsL[0].volumeCB
+    assert loopData_d.numel() >= N_GAMMA * 2 * eVecsL[0].volumeCB
     L = desc_array(eVecsL)
     R = L if eVecsR is eVecsL else desc_array(eVecsR)
     sg = (ctypes.c_double * n)(*[float(s) for s in sigmas])
-    _lib.check(_lib.load().mugiq_hip_perform_loop_contraction_batched(loopData_d.data_ptr(), L, R, sg, n, _stream()))
+    _lib.check(_lib.load().mugiq_hip_perform_loop_contraction_batched_mixed(loopData_d.data_ptr(), _prec_of(loopData_d), L, R, sg, n,
+                                                                             _stream()))
 
 
 def performCovariantDisplacementVector(dst, src, gauge, dispDir, dispSign, commDim=(0, 0, 0, 0)):
@@ -134,8 +136,8 @@ def displacedLoopContractionFused(loopData_d, eVecs, sigmas, pathLinkFields, kVa
     sg = (ctypes.c_double * n)(*[float(s) for s in sigmas])
     links = (ctypes.c_void_p * nk)(*[f.data.data_ptr() for f in pathLinkFields])
     kv = (ctypes.c_int * nk)(*[int(k) for k in kValues])
-    _lib.check(_lib.load().mugiq_hip_displaced_loop_contraction_fused(
-        loopData_d.data_ptr(), d, sg, n, links, kv, nk, int(dispDir), int(dispSign), _lib.int4(commDim),
+    _lib.check(_lib.load().mugiq_hip_displaced_loop_contraction_fused_mixed(
+        loopData_d.data_ptr(), _prec_of(loopData_d), d, sg, n, links, kv, nk, int(dispDir), int(dispSign), _lib.int4(commDim),
         ghostLayers_d.data_ptr() if ghostLayers_d is not None else None, int(layers), _stream()))
 
 

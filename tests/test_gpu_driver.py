@@ -185,3 +185,36 @@ def test_extended_gauge_from_qdp_host_single_process(hip, prec):
         g = hip.GaugeField(X, R, prec).set_from_qdp_host(orc.gauge_to_qdp_host(U_loc))
         exp = orc.extended_gauge_from_global(U_lex, (0, 0, 0, 0), (1, 1, 1, 1), R).astype(cdt)
         assert np.array_equal(g.get_logical(), exp), R
+
+
+@pytest.mark.parametrize("order,calc", [(4, "opt"), (2, "basic")])
+def test_driver_mixed_precision(hip, order, calc):
+    """fp32 eigenvectors + links, fp64 loop buffers / FT (MugiqLoopParam.loopPrecision = 8)."""
+    X = (4, 4, 4, 8)
+    nev = 4
+    ev, Uo, f, U = _setup(hip, X, nev, 4, order, 91)
+    sg = sigmas(nev)
+    moms = momenta_p2_le(2)
+    prm = hip.MugiqLoopParam(FTSign=1, doMomProj=True, gauge=U, momMatrix=[list(m) for m in moms], Nmom=len(moms), loopPrecision=8,
+                             calcType=hip.LOOP_CALC_TYPE_BASIC_KERNEL if calc == "basic" else hip.LOOP_CALC_TYPE_OPT_KERNEL)
+    prm.set_displace_entry_string("+x:1,2;-t:2")
+    loop = hip.Loop_Mugiq(prm, f, sg)
+    assert loop.precision == 4 and loop.loopPrecision == 8
+    loop.computeCoarseLoop()
+    pos = loop.dataPos_d
+    assert pos.dtype == torch.complex128
+    cprm = orc.LoopComputeParam(["+x", "-t"], [1, 2], [2, 2])
+    sg32 = np.float32(sg).astype(np.float64)
+    ref_pos = orc.compute_loop_position_space(ev, sg32, cprm, Uo, X)
+    V = int(np.prod(X))
+    # ultra-local slot: only the inputs are fp32 -> fp64-exact; displaced slots carry the fp32 link products
+    assert rel_err(pos[:16 * V].cpu().numpy(), ref_pos[:16 * V]) < 1e-13
+    assert rel_err(pos.cpu().numpy(), ref_pos) < 2e-6
+    locV3 = X[0] * X[1] * X[2]
+    ref_mom = orc.momentum_projection_local(orc.convert_idx_order_map_gamma(ref_pos, cprm.nData, cprm.nLoop, 2, V // 2, X),
+                                            orc.phase_matrix(moms, locV3, 1, X, X), X[3], cprm.nData, locV3, len(moms))
+    assert loop.dataMom_bcast.dtype == np.complex128 and rel_err(loop.dataMom_bcast, ref_mom) < 2e-6
+    loop.close()
+    with pytest.raises(hip.MugiqHipError):
+        ev8, _, f8, U8 = _setup(hip, X, 1, 8, 2, 1)
+        hip.Loop_Mugiq(hip.MugiqLoopParam(loopPrecision=4), f8, sg[:1])        # fp32 loops over fp64 eigenvectors

@@ -300,3 +300,34 @@ def test_errors_are_loud(hip):
     with pytest.raises(hip.MugiqHipError):
         big = torch.zeros(17 * 256, dtype=torch.complex128, device="cuda")
         hip.convertIdxOrder_mapGamma(torch.zeros_like(big), big, 17, 1, 2, 128, X)     # nData != 16*nLoop
+
+
+@pytest.mark.parametrize("order", [2, 4])
+def test_mixed_precision_contraction_fp32_storage_fp64_accumulation(hip, order):
+    """configs[3] / f3: fp32 eigenvectors, all arithmetic and the loop buffer in fp64 -> equals the fp64 oracle on
+    the fp32-rounded inputs to fp64 rounding (1e-13), far below the 1e-5 the plain fp32 path is held to."""
+    X = (4, 6, 4, 8)
+    rng = np.random.default_rng(55)
+    nev = 7
+    V = int(np.prod(X))
+    evL = [orc.lex_to_eo(random_spinor_lex(rng, X), X) for _ in range(nev)]
+    evR = [orc.lex_to_eo(random_spinor_lex(rng, X), X) for _ in range(nev)]
+    sg = sigmas(nev)
+    fL = [_field(hip, v, X, 4, order) for v in evL]
+    fR = [_field(hip, v, X, 4, order) for v in evR]
+    ref_lr = np.zeros(16 * V, dtype=np.complex128)
+    ref_ll = np.zeros(16 * V, dtype=np.complex128)
+    for n in range(nev):
+        s32 = float(np.float32(sg[n]))                                     # (Float) eVals_sigma[n]
+        orc.loop_contract(ref_lr, _rounded(evL[n], 4), _rounded(evR[n], 4), s32)
+        orc.loop_contract(ref_ll, _rounded(evL[n], 4), _rounded(evL[n], 4), s32)
+    a = torch.zeros(16 * V, dtype=torch.complex128, device="cuda")
+    hip.performLoopContractionBatched(a, fL, fR, sg)
+    assert rel_err(a.cpu().numpy(), ref_lr) < 1e-13
+    b = torch.zeros(16 * V, dtype=torch.complex128, device="cuda")
+    hip.performLoopContractionBatched(b, fL, fL, sg)
+    assert rel_err(b.cpu().numpy(), ref_ll) < 1e-13
+    # fp32 loop buffer over fp64 fields is refused
+    f64 = [_field(hip, v, X, 8, order) for v in evL[:1]]
+    with pytest.raises(hip.MugiqHipError):
+        hip.performLoopContractionBatched(torch.zeros(16 * V, dtype=torch.complex64, device="cuda"), f64, f64, sg[:1])
