@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--nev", type=int, default=200)
     ap.add_argument("--precision", type=int, default=8, choices=[4, 8])
     ap.add_argument("--order", type=int, default=2, choices=[2, 4])
+    ap.add_argument("--loop-precision", type=int, default=0, choices=[0, 4, 8],
+                    help="8 with --precision 4 = mixed precision (fp32 storage, fp64 accumulation; configs[3])")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -133,7 +135,8 @@ def main():
     B = prec
     sig = 0.01 + 0.002 * np.arange(nev)
     big, fields = make_evecs(hip, X, nev, prec, order, device, seed=777 + rank)
-    cdt = torch.complex128 if prec == 8 else torch.complex64
+    lprec = a.loop_precision or prec
+    cdt = torch.complex128 if lprec == 8 else torch.complex64
     loop = torch.zeros(16 * V, dtype=cdt, device=device)
 
     def step():
@@ -168,11 +171,12 @@ def main():
     ms_per_step = elapsed * 1e3 / a.steps
     value = world * V / (ms_per_step * 1e-3)
 
-    alg_bytes = V * (nev * 24 * B + 32 * B)          # per site N_ev*24*B read + 32*B written
+    alg_bytes = V * (nev * 24 * B + 32 * lprec)      # per site N_ev*24*B read + 32*B written
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    workload = "%dx%dx%dx%d %s N_ev=%d ultra-local 16-gamma loop (order FLOAT%d)" % (X + ("fp64" if prec == 8 else "fp32", nev, order))
+    workload = "%dx%dx%dx%d %s N_ev=%d ultra-local 16-gamma loop (order FLOAT%d)" % (
+        X + ("fp64" if prec == 8 else ("fp32" if lprec == 4 else "fp32-storage/fp64-accumulate"), nev, order))
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
@@ -184,7 +188,7 @@ def main():
     out = {
         "metric": "loop_trace_sites_per_sec", "value": value, "unit": "sites/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64" if prec == 8 else "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f64" if lprec == 8 else "f32", "data": "synthetic",
         "config": {"workload": workload, "local_lattice": list(X), "n_ev": nev, "n_gamma": 16,
                    "site_evecs_per_s": value * nev, "partition": "independent site blocks, one per rank"},
         "roofline": {"bound": "hbm", "kernel": "loop_contract_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
