@@ -214,6 +214,46 @@ int mugiq_hip_momentum_projection(void *dataMom_d, const void *dataPosMP_d, cons
                                   int locT, int nData, long long locV3, int Nmom, int precision,
                                   void *workspace_d, size_t workspace_bytes, void *stream);
 
+/* ==== f2: MG coarse path -- Loop_Mugiq::prolongateEvec (lib/loop_mugiq.cpp:277-319) = QUDA Transfer::P ============== */
+
+/* A coarse-grid colour-spinor in QUDA's FLOAT2 order (what Eigsolve_Mugiq hands over when computeCoarse is set,
+ * lib/loop_mugiq.cpp:482): nSpin = 4/spin_block_size = 2 chiralities, nColor = n_vec; complex index of (s, c) at
+ * (parity, x_cb): parity*parity_offset + (s*nColor + c)*stride + x_cb, even-odd on the coarse lattice X. */
+typedef struct MugiqHipCoarseField_s {
+  void *data;
+  int precision; /* 4 | 8 */
+  int nSpin;     /* 2 */
+  int nColor;    /* n_vec */
+  int volumeCB;
+  int stride;
+  int X[4];      /* coarse lattice dims = fine dims / geo_block_size, all even */
+  int64_t parity_offset;
+} MugiqHipCoarseField;
+
+/* One level of QUDA's Transfer: the block-orthonormal null vectors V as a fine field with a packed vector index,
+ * FieldOrderCB<Float,4,3,n_vec,FLOAT2>: complex index of V(parity, x_cb; s, c, j) =
+ * parity*parity_offset + ((3*s + c)*nVec + j)*stride + x_cb.  (Producing V is QUDA's MG setup: out of scope.) */
+typedef struct MugiqHipTransfer_s {
+  const void *V;
+  int precision;       /* 4 | 8 */
+  int nVec;            /* mg_param.n_vec[0], default 24 (tests/loop.cpp:492) */
+  int geoBlockSize[4]; /* mg_param.geo_block_size[0], default 4^4 (tests/loop.cpp:471) */
+  int spinBlockSize;   /* 2 (tests/loop.cpp:569) */
+  int X[4];            /* fine local dims */
+  int stride;          /* fine volumeCB + pad */
+  int64_t parity_offset;
+} MugiqHipTransfer;
+
+/* fine_h[n](x; s, c) = sum_j V(x; s, c, j) * coarse_h[n](X(x); s/spinBlockSize, j) for all n < nVec in one launch
+ * (the reference prolongs one eigenvector per call, and again for every displacement entry: lib/loop_mugiq.cpp:482). */
+int mugiq_hip_prolongate_batched(const MugiqHipSpinorField *fine_h, const MugiqHipCoarseField *coarse_h, int nVec,
+                                 const MugiqHipTransfer *transfer, void *stream);
+/* Ultra-local loop of the MG path without materialising the fine vectors:
+ * loopData += sum_n (1/sigma_n) (P c_n)^dag G (P c_n).  loopPrecision as in the *_mixed entry points. */
+int mugiq_hip_prolongate_contract_batched(void *loopData_d, int loopPrecision, const MugiqHipCoarseField *coarse_h,
+                                          const double *sigma_h, int nVec, const MugiqHipTransfer *transfer,
+                                          void *stream);
+
 /* ==== host-side driver: the Loop_Mugiq / Displace classes of the reference ========================================= */
 
 /* include/enum_mugiq.h:35-41.  calcType is parsed but never read by the reference's live code; here it selects
@@ -291,6 +331,15 @@ typedef struct MugiqHipLoop_s MugiqHipLoop;
  * The descriptors are copied; the eigenvector memory stays the caller's. */
 int mugiq_hip_loop_create(MugiqHipLoop **loop, const MugiqHipLoopParam *param, const MugiqHipSpinorField *eVecs_h,
                           const double *eVals_sigma_h, int nEv, const MugiqHipComm *comm, void *stream);
+/* The same with eigsolve->useMGenv && eigsolve->computeCoarse (lib/loop_mugiq.cpp:42,482; configs[4]): the
+ * eigenvectors are COARSE fields and are prolonged with `transfer` (mugiq_hip_prolongate_batched) -- once, not once
+ * per displacement entry; without displacement entries the ultra-local loop runs through
+ * mugiq_hip_prolongate_contract_batched and the fine vectors are never stored.  fineFieldOrder must be 2
+ * ("Vector prolongation requires fieldOrder = FLOAT2", lib/loop_mugiq.cpp:283). */
+int mugiq_hip_loop_create_coarse(MugiqHipLoop **loop, const MugiqHipLoopParam *param,
+                                 const MugiqHipCoarseField *coarseEvecs_h, const double *eVals_sigma_h, int nEv,
+                                 const MugiqHipTransfer *transfer, int fineFieldOrder, const MugiqHipComm *comm,
+                                 void *stream);
 /* Loop_Mugiq::computeCoarseLoop()  lib/loop_mugiq.cpp:439-525 (position-space loops for the ultra-local case and
  * every displacement entry, then performMomentumProjection :322-434 if doMomProj).  Synchronises `stream`. */
 int mugiq_hip_loop_compute(MugiqHipLoop *loop);

@@ -7,11 +7,11 @@ from . import _lib
 
 _lib.load()
 
-from .fields import SpinorField, GaugeField, FLOAT2, FLOAT4  # noqa: E402
+from .fields import SpinorField, GaugeField, CoarseField, Transfer, FLOAT2, FLOAT4  # noqa: E402
 from .operators import (  # noqa: E402
     copyGammaCoeffStructToSymbol, copyGammaMapStructToSymbol, gammaTables, GammaName,
     performLoopContraction, performLoopContractionBatched, performCovariantDisplacementVector, packFace,
-    createPhaseMatrixGPU, convertIdxOrder_mapGamma, momentumProjection, packFaceLayers, displacedLoopContractionFused, probeReadBandwidth,
+    createPhaseMatrixGPU, convertIdxOrder_mapGamma, momentumProjection, packFaceLayers, displacedLoopContractionFused, probeReadBandwidth, prolongateEvecs, prolongateContractBatched,
     DispDir, DispSignMinus, DispSignPlus, LOOP_FT_SIGN_MINUS, LOOP_FT_SIGN_PLUS, DisplaceFlagArray,
 )
 from ._lib import MugiqHipError, LIB_PATH  # noqa: E402

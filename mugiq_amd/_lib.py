@@ -36,6 +36,18 @@ class GaugeDesc(ctypes.Structure):
                 ("parity_offset", ctypes.c_int64)]
 
 
+class CoarseDesc(ctypes.Structure):
+    """MugiqHipCoarseField (include/mugiq_hip.h)."""
+    _fields_ = [("data", ctypes.c_void_p), ("precision", ctypes.c_int), ("nSpin", ctypes.c_int), ("nColor", ctypes.c_int),
+                ("volumeCB", ctypes.c_int), ("stride", ctypes.c_int), ("X", ctypes.c_int * 4), ("parity_offset", ctypes.c_int64)]
+
+
+class TransferDesc(ctypes.Structure):
+    """MugiqHipTransfer (include/mugiq_hip.h)."""
+    _fields_ = [("V", ctypes.c_void_p), ("precision", ctypes.c_int), ("nVec", ctypes.c_int), ("geoBlockSize", ctypes.c_int * 4),
+                ("spinBlockSize", ctypes.c_int), ("X", ctypes.c_int * 4), ("stride", ctypes.c_int), ("parity_offset", ctypes.c_int64)]
+
+
 _I4 = ctypes.POINTER(ctypes.c_int)
 _VP = ctypes.c_void_p
 _SP = ctypes.POINTER(SpinorDesc)
@@ -76,9 +88,15 @@ SIGNATURES = {
     "mugiq_hip_displaced_loop_contraction_fused": (ctypes.c_int, [_VP, _SP, ctypes.POINTER(ctypes.c_double), ctypes.c_int,
                                                                   ctypes.POINTER(ctypes.c_void_p), _I4, ctypes.c_int,
                                                                   ctypes.c_int, ctypes.c_int, _I4, _VP, ctypes.c_int, _VP]),
+    "mugiq_hip_prolongate_batched": (ctypes.c_int, [_SP, ctypes.POINTER(CoarseDesc), ctypes.c_int, ctypes.POINTER(TransferDesc), _VP]),
+    "mugiq_hip_prolongate_contract_batched": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.POINTER(CoarseDesc), ctypes.POINTER(ctypes.c_double),
+                                                             ctypes.c_int, ctypes.POINTER(TransferDesc), _VP]),
     # driver (struct pointers are passed with ctypes.byref; see mugiq_amd/loop.py for the struct definitions)
     "mugiq_hip_loop_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _VP, _SP, ctypes.POINTER(ctypes.c_double),
                                              ctypes.c_int, _VP, _VP]),
+    "mugiq_hip_loop_create_coarse": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _VP, ctypes.POINTER(CoarseDesc),
+                                                    ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.POINTER(TransferDesc),
+                                                    ctypes.c_int, _VP, _VP]),
     "mugiq_hip_loop_compute": (ctypes.c_int, [_VP]),
     "mugiq_hip_loop_get_info": (ctypes.c_int, [_VP, _VP]),
     "mugiq_hip_loop_get_entry": (ctypes.c_int, [_VP, ctypes.c_int, _I4]),

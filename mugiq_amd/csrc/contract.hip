@@ -34,43 +34,6 @@ template <typename A> struct ContractArgs {
   int64_t parity_offset;
 };
 
-// acc (full 4x4) += conj(l[be,c]) * (s * r[al,c])
-template <typename F> __device__ inline void accumulate_full(Cplx<F> acc[16], const Cplx<F> l[12], const Cplx<F> r[12], F s) {
-  Cplx<F> sr[12];
-#pragma unroll
-  for (int k = 0; k < 12; k++) sr[k] = Cplx<F>{s * r[k].re, s * r[k].im};
-#pragma unroll
-  for (int be = 0; be < 4; be++)
-#pragma unroll
-    for (int al = 0; al < 4; al++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) cmadd_conj(acc[be * 4 + al], l[be * 3 + c], sr[al * 3 + c]);
-}
-
-// Hermitian case (l == r): diagonal kept in diag[4] (real), strict upper triangle in up[6]
-// pair order (be,al): (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
-template <typename F> __device__ inline void accumulate_herm(F diag[4], Cplx<F> up[6], const Cplx<F> v[12], F s) {
-  Cplx<F> sv[12];
-#pragma unroll
-  for (int k = 0; k < 12; k++) sv[k] = Cplx<F>{s * v[k].re, s * v[k].im};
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      diag[a] = fma(v[a * 3 + c].re, sv[a * 3 + c].re, diag[a]);
-      diag[a] = fma(v[a * 3 + c].im, sv[a * 3 + c].im, diag[a]);
-    }
-  int p = 0;
-#pragma unroll
-  for (int be = 0; be < 4; be++)
-#pragma unroll
-    for (int al = be + 1; al < 4; al++) {
-#pragma unroll
-      for (int c = 0; c < 3; c++) cmadd_conj(up[p], v[be * 3 + c], sv[al * 3 + c]);
-      p++;
-    }
-}
-
 // streaming load of one site's 12 complex; NT = non-temporal (the eigenvectors are read exactly once)
 template <typename F, typename A, int ORDER, bool NT>
 __device__ inline void load_spinor(Cplx<A> v[12], const void *body, int64_t parity_offset, int stride, int parity, int x_cb) {
@@ -92,21 +55,6 @@ __device__ inline void load_spinor(Cplx<A> v[12], const void *body, int64_t pari
       v[2 * j] = Cplx<A>{(A)t.x, (A)t.y};
       v[2 * j + 1] = Cplx<A>{(A)t.z, (A)t.w};
     }
-  }
-}
-
-// trace = sum_{s2} row_value[iG][s2] * resG[s2][column_index[iG][s2]]; loopData[tid + V*iG] += trace (:110-120)
-template <typename F> __device__ inline void trace_and_store(Cplx<F> *loop, const Cplx<F> acc[16], int V, int site) {
-#pragma unroll
-  for (int iG = 0; iG < 16; iG++) {
-    Cplx<F> t{F(0), F(0)};
-#pragma unroll
-    for (int s2 = 0; s2 < 4; s2++) add_phase(t, kGammaPhase[iG][s2], acc[s2 * 4 + kGammaColumn[iG][s2]]);
-    Cplx<F> *out = loop + (int64_t)V * iG + site;
-    Cplx<F> o = *out;
-    o.re += t.re;
-    o.im += t.im;
-    *out = o;
   }
 }
 

@@ -68,6 +68,11 @@ struct MugiqHipLoop_s {
   void *dataPos_d = nullptr, *dataPosMP_d = nullptr, *dataMom_d = nullptr, *phaseMatrix_d = nullptr;
   void *dataPos = nullptr, *dataMom_h = nullptr, *dataMom = nullptr, *dataMom_bcast = nullptr;
   bool dataPosCopied = false, momProjDone = false, computed = false;
+  // ---- MG coarse path (eigsolve->computeCoarse): coarse eigenvectors + one Transfer level (lib/loop_mugiq.cpp:277-319,482)
+  bool coarseMode = false;
+  std::vector<MugiqHipCoarseField> coarseVecs;
+  MugiqHipTransfer transfer;
+  void *fineStore = nullptr;  // prolonged eigenvectors, owned; NULL when only the fused prolong-contract is needed
   // ---- displacement scratch (Displace::auxDispVec and friends)
   std::vector<void *> scratch;  // device allocations freed in the destructor
 
@@ -476,11 +481,66 @@ int mugiq_hip_loop_create(MugiqHipLoop **out, const MugiqHipLoopParam *p, const 
   return MUGIQ_HIP_SUCCESS;
 }
 
+// Loop_Mugiq with eigsolve->useMGenv && eigsolve->computeCoarse (lib/loop_mugiq.cpp:42,482): the eigenvectors live on
+// the coarse grid and are prolonged with the MG transfer operator before they are contracted.
+int mugiq_hip_loop_create_coarse(MugiqHipLoop **out, const MugiqHipLoopParam *p, const MugiqHipCoarseField *coarseEvecs_h,
+                                 const double *eVals_sigma_h, int nEv, const MugiqHipTransfer *transfer, int fineFieldOrder,
+                                 const MugiqHipComm *comm, void *stream) {
+  const char *who = "Loop_Mugiq(coarse)";
+  MUGIQ_REQUIRE(out && p && coarseEvecs_h && eVals_sigma_h && transfer, "%s: NULL argument", who);
+  MUGIQ_REQUIRE(nEv >= 1, "%s: nEv = %d must be >= 1", who, nEv);
+  // the reference insists on FLOAT2 for the MG-coarse path (lib/loop_mugiq.cpp:283, lib/interface_mugiq.cpp:226-230)
+  MUGIQ_REQUIRE(fineFieldOrder == 2, "%s: Vector prolongation requires fieldOrder = FLOAT2", who);
+  MUGIQ_REQUIRE(transfer->V && (transfer->precision == 4 || transfer->precision == 8), "%s: invalid transfer", who);
+  *out = nullptr;
+  long long vol = 1;
+  for (int d = 0; d < 4; d++) {
+    MUGIQ_REQUIRE(transfer->X[d] > 0 && (transfer->X[d] & 1) == 0, "%s: fine X[%d] = %d must be positive and even", who, d, transfer->X[d]);
+    vol *= transfer->X[d];
+  }
+  const int volumeCB = (int)(vol / 2);
+  const bool needFine = (p->doNonLocal && p->nDispEntries > 0) || p->calcType == MUGIQ_HIP_LOOP_CALC_TYPE_BASIC_KERNEL;
+  const size_t fieldBytes = (size_t)24 * volumeCB * 2 * (size_t)transfer->precision;
+  void *store = nullptr;
+  if (needFine) MUGIQ_CHECK_HIP(hipMalloc(&store, fieldBytes * (size_t)nEv));
+  std::vector<MugiqHipSpinorField> fine(nEv);
+  for (int n = 0; n < nEv; n++) {
+    MugiqHipSpinorField f{};
+    // without fine storage the descriptors only carry the geometry: the ultra-local loop runs through the fused
+    // prolong-contract kernel and never dereferences them
+    f.data = needFine ? static_cast<char *>(store) + fieldBytes * (size_t)n : reinterpret_cast<void *>(uintptr_t(16));
+    f.precision = transfer->precision;
+    f.field_order = fineFieldOrder;
+    f.nParity = 2;
+    f.volumeCB = volumeCB;
+    f.stride = volumeCB;
+    f.parity_offset = (int64_t)12 * volumeCB;
+    for (int d = 0; d < 4; d++) f.X[d] = transfer->X[d];
+    fine[n] = f;
+  }
+  MugiqHipLoop *lp = nullptr;
+  int st = mugiq_hip_loop_create(&lp, p, fine.data(), eVals_sigma_h, nEv, comm, stream);
+  if (st) {
+    if (store) (void)hipFree(store);
+    return st;
+  }
+  lp->coarseMode = true;
+  lp->coarseVecs.assign(coarseEvecs_h, coarseEvecs_h + nEv);
+  lp->transfer = *transfer;
+  lp->fineStore = store;
+  *out = lp;
+  return MUGIQ_HIP_SUCCESS;
+}
+
 int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
   MUGIQ_REQUIRE(lp != nullptr, "computeCoarseLoop: NULL loop handle");
   int st = MUGIQ_HIP_SUCCESS;
   const size_t cb = lp->loopBytes();
   const bool basic = lp->calcType == MUGIQ_HIP_LOOP_CALC_TYPE_BASIC_KERNEL;
+  if (lp->coarseMode && lp->fineStore) {
+    // prolongateEvec for every eigenvector, once (the reference repeats it per displacement entry, lib/loop_mugiq.cpp:482)
+    if ((st = mugiq_hip_prolongate_batched(lp->eVecs.data(), lp->coarseVecs.data(), lp->nEv, &lp->transfer, lp->stream))) return st;
+  }
   for (int id = -1; id < lp->nDispEntries; id++) {  // lib/loop_mugiq.cpp:455
     long long bufOffset;
     size_t bufByteSize;
@@ -493,7 +553,11 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
     }
     void *slot0 = static_cast<char *>(lp->dataPos_d) + (size_t)bufOffset * cb;
     MUGIQ_CHECK_HIP(hipMemsetAsync(slot0, 0, bufByteSize, lp->stream));  // :476
-    if (id == -1) {
+    if (id == -1 && lp->coarseMode && !lp->fineStore) {
+      // MG ultra-local loop without materialising the fine vectors
+      st = mugiq_hip_prolongate_contract_batched(slot0, lp->loopPrecision, lp->coarseVecs.data(), lp->sigma.data(), lp->nEv,
+                                                 &lp->transfer, lp->stream);
+    } else if (id == -1) {
       if (basic) {
         for (int n = 0; n < lp->nEv && !st; n++)  // :501-502
           st = mugiq_hip_perform_loop_contraction_batched_mixed(slot0, lp->loopPrecision, &lp->eVecs[n], &lp->eVecs[n], &lp->sigma[n], 1,
@@ -627,6 +691,7 @@ int mugiq_hip_loop_destroy(MugiqHipLoop *lp) {  // freeDataMemory, lib/loop_mugi
   free(lp->dataMom_h);
   free(lp->dataMom);
   free(lp->dataPos);
+  if (lp->fineStore) (void)hipFree(lp->fineStore);
   if (lp->dataPos_d) (void)hipFree(lp->dataPos_d);
   if (lp->dataPosMP_d) (void)hipFree(lp->dataPosMP_d);
   if (lp->dataMom_d) (void)hipFree(lp->dataMom_d);

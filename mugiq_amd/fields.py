@@ -176,6 +176,92 @@ class GaugeField:
         return self
 
 
+class CoarseField:
+    """Coarse-grid colour-spinor (nSpin 2, nColor n_vec) in FLOAT2 order: a coarse eigenvector of the MG path."""
+
+    def __init__(self, Xc, n_vec, precision=8, pad=0, device="cuda"):
+        self.X = tuple(int(x) for x in Xc)
+        assert all(x > 0 and x % 2 == 0 for x in self.X), "coarse dims must be even"
+        self.n_vec = int(n_vec)
+        self.precision = int(precision)
+        self.volumeCB = int(np.prod(self.X)) // 2
+        self.stride = self.volumeCB + int(pad)
+        self.parity_offset = 2 * self.n_vec * self.stride
+        self.device = torch.device(device)
+        self.data = torch.zeros(2 * self.parity_offset, dtype=_cdtype(precision), device=self.device)
+
+    def desc(self):
+        d = _lib.CoarseDesc()
+        d.data = self.data.data_ptr()
+        d.precision, d.nSpin, d.nColor = self.precision, 2, self.n_vec
+        d.volumeCB, d.stride, d.parity_offset = self.volumeCB, self.stride, self.parity_offset
+        for i in range(4):
+            d.X[i] = self.X[i]
+        return d
+
+    def set_logical(self, phi):
+        """phi: [2, volCB_c, 2, n_vec]"""
+        phi = np.asarray(phi)
+        assert phi.shape == (2, self.volumeCB, 2, self.n_vec)
+        p = np.arange(2).reshape(2, 1, 1, 1)
+        x = np.arange(self.volumeCB).reshape(1, -1, 1, 1)
+        s = np.arange(2).reshape(1, 1, 2, 1)
+        c = np.arange(self.n_vec).reshape(1, 1, 1, -1)
+        buf = np.zeros(2 * self.parity_offset, dtype=_np_cdtype(self.precision))
+        buf[p * self.parity_offset + (s * self.n_vec + c) * self.stride + x] = phi.astype(buf.dtype)
+        self.data.copy_(torch.from_numpy(buf))
+        return self
+
+
+class Transfer:
+    """One level of QUDA's Transfer as the hot path sees it: the block-orthonormal null vectors V on the fine grid
+    (packed vector index), the aggregate size and the spin blocking."""
+
+    def __init__(self, X, n_vec=24, geo_block_size=(4, 4, 4, 4), spin_block_size=2, precision=8, pad=0, device="cuda"):
+        self.X = tuple(int(x) for x in X)
+        self.n_vec = int(n_vec)
+        self.geo_block_size = tuple(int(b) for b in geo_block_size)
+        self.spin_block_size = int(spin_block_size)
+        self.precision = int(precision)
+        self.volumeCB = int(np.prod(self.X)) // 2
+        self.stride = self.volumeCB + int(pad)
+        self.parity_offset = 12 * self.n_vec * self.stride
+        self.device = torch.device(device)
+        self.V = torch.zeros(2 * self.parity_offset, dtype=_cdtype(precision), device=self.device)
+        self.Xc = tuple(self.X[d] // self.geo_block_size[d] for d in range(4))
+
+    def desc(self):
+        d = _lib.TransferDesc()
+        d.V = self.V.data_ptr()
+        d.precision, d.nVec, d.spinBlockSize = self.precision, self.n_vec, self.spin_block_size
+        d.stride, d.parity_offset = self.stride, self.parity_offset
+        for i in range(4):
+            d.X[i] = self.X[i]
+            d.geoBlockSize[i] = self.geo_block_size[i]
+        return d
+
+    def set_logical(self, V):
+        """V: [2, volCB, 4, 3, n_vec]"""
+        V = np.asarray(V)
+        assert V.shape == (2, self.volumeCB, 4, 3, self.n_vec)
+        p = np.arange(2).reshape(2, 1, 1, 1, 1)
+        x = np.arange(self.volumeCB).reshape(1, -1, 1, 1, 1)
+        s = np.arange(4).reshape(1, 1, 4, 1, 1)
+        c = np.arange(3).reshape(1, 1, 1, 3, 1)
+        j = np.arange(self.n_vec).reshape(1, 1, 1, 1, -1)
+        buf = np.zeros(2 * self.parity_offset, dtype=_np_cdtype(self.precision))
+        buf[p * self.parity_offset + ((3 * s + c) * self.n_vec + j) * self.stride + x] = V.astype(buf.dtype)
+        self.V.copy_(torch.from_numpy(buf))
+        return self
+
+
+def coarse_desc_array(fields):
+    arr = (_lib.CoarseDesc * len(fields))()
+    for i, f in enumerate(fields):
+        arr[i] = f.desc()
+    return arr
+
+
 def desc_array(fields):
     arr = (_lib.SpinorDesc * len(fields))()
     for i, f in enumerate(fields):

@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from .comm import device_bytes
-from .fields import GaugeField, desc_array
+from .fields import GaugeField, desc_array, coarse_desc_array
 
 LOOP_CALC_TYPE_BLAS, LOOP_CALC_TYPE_OPT_KERNEL, LOOP_CALC_TYPE_BASIC_KERNEL = 0, 1, 2   # include/enum_mugiq.h:35-41
 
@@ -110,7 +110,8 @@ class Loop_Mugiq:
     """Loop_Mugiq<Float, order>(loopParams, eigsolve): Float/order come from the eigenvector fields;
     `eVecs` / `eVals_sigma` are what the reference reads out of Eigsolve_Mugiq (lib/loop_mugiq.cpp:442,479)."""
 
-    def __init__(self, loopParams, eVecs, eVals_sigma, comm=None):
+    def __init__(self, loopParams, eVecs, eVals_sigma, comm=None, transfer=None):
+        """`transfer` given: eVecs are CoarseField eigenvectors (eigsolve->computeCoarse) prolonged with it."""
         lib = _lib.load()
         self._keep = []
         p = _CLoopParam()
@@ -143,14 +144,20 @@ class Loop_Mugiq:
             p.gauge = ctypes.pointer(g)
         p.loopPrecision = int(loopParams.loopPrecision)
         self.eVecs = list(eVecs)
-        descs = desc_array(self.eVecs)
         sg = (ctypes.c_double * len(self.eVecs))(*[float(s) for s in eVals_sigma])
         self.comm = comm
         c = comm.c_struct() if comm is not None else None
         self._handle = ctypes.c_void_p()
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(lib.mugiq_hip_loop_create(ctypes.byref(self._handle), ctypes.byref(p), descs, sg, len(self.eVecs),
-                                             ctypes.byref(c) if c is not None else None, stream))
+        if transfer is None:
+            _lib.check(lib.mugiq_hip_loop_create(ctypes.byref(self._handle), ctypes.byref(p), desc_array(self.eVecs), sg,
+                                                 len(self.eVecs), ctypes.byref(c) if c is not None else None, stream))
+        else:
+            t = transfer.desc()
+            self._keep += [t, transfer]
+            _lib.check(lib.mugiq_hip_loop_create_coarse(ctypes.byref(self._handle), ctypes.byref(p), coarse_desc_array(self.eVecs),
+                                                        sg, len(self.eVecs), ctypes.byref(t), 2,
+                                                        ctypes.byref(c) if c is not None else None, stream))
         info = _CLoopInfo()
         _lib.check(lib.mugiq_hip_loop_get_info(self._handle, ctypes.byref(info)))
         self.info = info

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .fields import SpinorField, GaugeField, desc_array
+from .fields import SpinorField, GaugeField, desc_array, coarse_desc_array
 
 N_GAMMA = 16
 DispDir = {"x": 0, "y": 1, "z": 2, "t": 3}          # include/enum_mugiq.h:72-78
@@ -144,3 +144,20 @@ def displacedLoopContractionFused(loopData_d, eVecs, sigmas, pathLinkFields, kVa
 def probeReadBandwidth(buf, nonTemporal=False):
     """Enqueue one streaming read of `buf` (a torch tensor); time it with events for the device's achievable GB/s."""
     _lib.check(_lib.load().mugiq_hip_probe_read_bandwidth(buf.data_ptr(), buf.numel() * buf.element_size(), int(nonTemporal), _stream()))
+
+
+def prolongateEvecs(fineEvecs, coarseEvecs, transfer):
+    """Loop_Mugiq::prolongateEvec (lib/loop_mugiq.cpp:277-319 = QUDA Transfer::P) for all eigenvectors in one launch."""
+    assert len(fineEvecs) == len(coarseEvecs) >= 1
+    t = transfer.desc()
+    _lib.check(_lib.load().mugiq_hip_prolongate_batched(desc_array(fineEvecs), coarse_desc_array(coarseEvecs), len(fineEvecs),
+                                                        ctypes.byref(t), _stream()))
+
+
+def prolongateContractBatched(loopData_d, coarseEvecs, sigmas, transfer):
+    """loopData += sum_n (1/sigma_n) (P c_n)^dag G (P c_n) without writing the fine vectors (MG ultra-local loop)."""
+    n = len(coarseEvecs)
+    t = transfer.desc()
+    sg = (ctypes.c_double * n)(*[float(s) for s in sigmas])
+    _lib.check(_lib.load().mugiq_hip_prolongate_contract_batched(loopData_d.data_ptr(), _prec_of(loopData_d), coarse_desc_array(coarseEvecs),
+                                                                 sg, n, ctypes.byref(t), _stream()))

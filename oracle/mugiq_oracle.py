@@ -549,3 +549,71 @@ def extended_gauge_from_global(U_lex, coords, grid, brd):
         blk = U_lex[mu][np.ix_(idx[3], idx[2], idx[1], idx[0])]
         out.append(lex_to_eo(blk, dimEx))
     return np.stack(out, axis=0)
+
+
+# ----------------------------------------------------------------------------------------------
+# f2  coarse -> fine prolongation   Loop_Mugiq::prolongateEvec, lib/loop_mugiq.cpp:277-319
+# ----------------------------------------------------------------------------------------------
+# The reference calls QUDA's Transfer::P (lib/loop_mugiq.cpp:310,314) on a 2-level hierarchy with
+# spin_block_size 2 (tests/loop.cpp:569), n_vec = 24 (:492) and 4^4 aggregates (:471).  ASSUMED from upstream
+# QUDA (lib/transfer.cpp createGeoMap/createSpinMap, include/kernels/prolongator.cuh):
+#   out(x; s, c) = sum_{j < n_vec} V(x; s, c, j) * in(X(x); s / spin_bs, j)
+# with X(x) the aggregate of x (coarse coordinates = fine coordinates / geo_bs, even-odd indexed on the coarse
+# lattice) and V the block-orthonormalised null vectors stored as a fine field with a packed vector index:
+#   V:       FieldOrderCB<Float, 4, 3, n_vec, FLOAT2>  plane index (3*s + c)*n_vec + j
+#   coarse:  FieldOrderCB<Float, 2, n_vec, 1, FLOAT2>  plane index  s*n_vec + j
+# Logical shapes here: V[2, volCB, 4, 3, n_vec], coarse[2, volCB_coarse, 2, n_vec].
+def fine_to_coarse_map(X, geo_bs):
+    """For each parity: (coarse parity, coarse x_cb) of every fine checkerboard site. Returns int arrays [2, volCB]."""
+    Xc = [X[d] // geo_bs[d] for d in range(4)]
+    vcb = int(np.prod(X)) // 2
+    cp = np.zeros((2, vcb), dtype=np.int64)
+    cx = np.zeros((2, vcb), dtype=np.int64)
+    for pty in range(2):
+        c = get_coords(np.arange(vcb), X, pty)
+        cc = c // np.asarray(geo_bs)
+        cp[pty] = cc.sum(axis=1) & 1
+        cx[pty] = lex_index(cc, Xc) >> 1
+    return cp, cx
+
+
+def prolongate(coarse, V, X, geo_bs=(4, 4, 4, 4), spin_bs=2):
+    """Transfer::P for one level: fine[2, volCB, 4, 3] from coarse[2, volCB_c, 4/spin_bs, n_vec]."""
+    nvec = V.shape[-1]
+    cp, cx = fine_to_coarse_map(X, geo_bs)
+    out = np.zeros(V.shape[:4], dtype=V.dtype)
+    for pty in range(2):
+        phi = coarse[cp[pty], cx[pty]]                       # [volCB, 2, n_vec]
+        for s in range(4):
+            for j in range(nvec):                            # rotateFineColor: j in order
+                out[pty, :, s, :] += V[pty, :, s, :, j] * phi[:, s // spin_bs, j, None]
+    return out
+
+
+def coarse_to_native(phi, stride=None, parity_offset=None):
+    """Logical [2, volCB_c, nSpin_c, nColor_c] -> flat FLOAT2 buffer (plane index s*nColor_c + c)."""
+    vcb, ns, nc = phi.shape[1], phi.shape[2], phi.shape[3]
+    stride = vcb if stride is None else stride
+    parity_offset = ns * nc * stride if parity_offset is None else parity_offset
+    buf = np.zeros(2 * parity_offset, dtype=phi.dtype)
+    x = np.arange(vcb)
+    for p in range(2):
+        for s in range(ns):
+            for c in range(nc):
+                buf[p * parity_offset + (s * nc + c) * stride + x] = phi[p, :, s, c]
+    return buf
+
+
+def nullvec_to_native(V, stride=None, parity_offset=None):
+    """Logical [2, volCB, 4, 3, n_vec] -> flat FLOAT2 buffer (plane index (3*s + c)*n_vec + j)."""
+    vcb, nvec = V.shape[1], V.shape[-1]
+    stride = vcb if stride is None else stride
+    parity_offset = 12 * nvec * stride if parity_offset is None else parity_offset
+    buf = np.zeros(2 * parity_offset, dtype=V.dtype)
+    x = np.arange(vcb)
+    for p in range(2):
+        for s in range(4):
+            for c in range(3):
+                for j in range(nvec):
+                    buf[p * parity_offset + ((3 * s + c) * nvec + j) * stride + x] = V[p, :, s, c, j]
+    return buf

@@ -218,3 +218,41 @@ def test_driver_mixed_precision(hip, order, calc):
     with pytest.raises(hip.MugiqHipError):
         ev8, _, f8, U8 = _setup(hip, X, 1, 8, 2, 1)
         hip.Loop_Mugiq(hip.MugiqLoopParam(loopPrecision=4), f8, sg[:1])        # fp32 loops over fp64 eigenvectors
+
+
+@pytest.mark.parametrize("calc,entries", [("opt", None), ("opt", "+z:1,2;-t:1"), ("basic", "+x:1")])
+def test_driver_mg_coarse_path(hip, calc, entries):
+    """configs[4]: coarse eigenvectors + transfer operator -> prolong -> loops (fused prolong-contract when no
+    displacement entries are requested), vs oracle prolongate + compute_loop_position_space."""
+    X, bs, nvec, nev = (8, 4, 4, 8), (4, 2, 2, 4), 6, 5
+    rng = np.random.default_rng(808)
+    vcb = int(np.prod(X)) // 2
+    Xc = [X[d] // bs[d] for d in range(4)]
+    vcbc = int(np.prod(Xc)) // 2
+    Vn = (rng.standard_normal((2, vcb, 4, 3, nvec)) + 1j * rng.standard_normal((2, vcb, 4, 3, nvec))) / np.sqrt(12.0 * nvec)
+    phis = [rng.standard_normal((2, vcbc, 2, nvec)) + 1j * rng.standard_normal((2, vcbc, 2, nvec)) for _ in range(nev)]
+    Uo = orc.extended_gauge_from_global(random_gauge_lex(rng, X), (0, 0, 0, 0), (1, 1, 1, 1), (0, 0, 0, 0))
+    sg = sigmas(nev)
+    T = hip.Transfer(X, nvec, bs, 2, 8).set_logical(Vn)
+    cf = [hip.CoarseField(Xc, nvec, 8).set_logical(p) for p in phis]
+    U = hip.GaugeField(X, (0, 0, 0, 0), 8).set_logical(Uo)
+    moms = momenta_p2_le(1)
+    prm = hip.MugiqLoopParam(FTSign=-1, doMomProj=True, momMatrix=[list(m) for m in moms], Nmom=len(moms), gauge=U,
+                             calcType=hip.LOOP_CALC_TYPE_BASIC_KERNEL if calc == "basic" else hip.LOOP_CALC_TYPE_OPT_KERNEL)
+    if entries:
+        prm.set_displace_entry_string(entries)
+        _, s, a, b = orc.parse_disp_entry_string(entries)
+        cprm = orc.LoopComputeParam(s, a, b)
+    else:
+        cprm = orc.LoopComputeParam(doNonLocal=False)
+    loop = hip.Loop_Mugiq(prm, cf, sg, transfer=T)
+    loop.computeCoarseLoop()
+    fine = [orc.prolongate(p, Vn, X, bs) for p in phis]
+    ref_pos = orc.compute_loop_position_space(fine, sg, cprm, Uo, X)
+    assert rel_err(loop.dataPos_d.cpu().numpy(), ref_pos) < 1e-12
+    V = int(np.prod(X))
+    locV3 = X[0] * X[1] * X[2]
+    ref_mom = orc.momentum_projection_local(orc.convert_idx_order_map_gamma(ref_pos, cprm.nData, cprm.nLoop, 2, V // 2, X),
+                                            orc.phase_matrix(moms, locV3, -1, X, X), X[3], cprm.nData, locV3, len(moms))
+    assert rel_err(loop.dataMom_bcast, ref_mom) < 1e-12
+    loop.close()

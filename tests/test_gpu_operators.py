@@ -331,3 +331,58 @@ def test_mixed_precision_contraction_fp32_storage_fp64_accumulation(hip, order):
     f64 = [_field(hip, v, X, 8, order) for v in evL[:1]]
     with pytest.raises(hip.MugiqHipError):
         hip.performLoopContractionBatched(torch.zeros(16 * V, dtype=torch.complex64, device="cuda"), f64, f64, sg[:1])
+
+
+# ---- f2: prolongator ---------------------------------------------------------------------------------------------
+def _mg_problem(X, bs, nvec, nev, seed):
+    rng = np.random.default_rng(seed)
+    vcb = int(np.prod(X)) // 2
+    Xc = [X[d] // bs[d] for d in range(4)]
+    vcbc = int(np.prod(Xc)) // 2
+    V = (rng.standard_normal((2, vcb, 4, 3, nvec)) + 1j * rng.standard_normal((2, vcb, 4, 3, nvec))) / np.sqrt(nvec * 12.0)
+    phis = [rng.standard_normal((2, vcbc, 2, nvec)) + 1j * rng.standard_normal((2, vcbc, 2, nvec)) for _ in range(nev)]
+    return V, phis, Xc
+
+
+@pytest.mark.parametrize("prec,order", CASES)
+@pytest.mark.parametrize("X,bs,nvec,nev", [((8, 8, 8, 8), (4, 4, 4, 4), 24, 5), ((8, 4, 12, 4), (2, 2, 3, 2), 6, 35), ((4, 4, 4, 6), (2, 2, 2, 1), 3, 2)])
+def test_prolongator_matches_oracle(hip, prec, order, X, bs, nvec, nev):
+    V, phis, Xc = _mg_problem(X, bs, nvec, nev, 71)
+    cdt = _np_c(prec)
+    V = V.astype(cdt)
+    phis = [p.astype(cdt) for p in phis]
+    T = hip.Transfer(X, nvec, bs, 2, prec).set_logical(V)
+    cf = [hip.CoarseField(Xc, nvec, prec).set_logical(p) for p in phis]
+    ff = [hip.SpinorField(X, prec, order) for _ in range(nev)]
+    hip.prolongateEvecs(ff, cf, T)
+    for n in range(nev):
+        exp = orc.prolongate(phis[n].astype(np.complex128), V.astype(np.complex128), X, bs)
+        assert rel_err(ff[n].get_logical(), exp) < (1e-14 if prec == 8 else 2e-6), n
+
+
+@pytest.mark.parametrize("prec,lprec", [(8, 8), (4, 4), (4, 8)])
+@pytest.mark.parametrize("X,bs,nvec,nev", [((8, 8, 8, 8), (4, 4, 4, 4), 24, 37), ((4, 4, 4, 6), (2, 2, 2, 1), 3, 2)])
+def test_fused_prolong_contract_matches_oracle(hip, prec, lprec, X, bs, nvec, nev):
+    """MG ultra-local loop: (P c_n)^dag G (P c_n) summed over n, fine vectors never written."""
+    V, phis, Xc = _mg_problem(X, bs, nvec, nev, 72)
+    cdt = _np_c(prec)
+    V = V.astype(cdt)
+    phis = [p.astype(cdt) for p in phis]
+    sg = sigmas(nev)
+    T = hip.Transfer(X, nvec, bs, 2, prec).set_logical(V)
+    cf = [hip.CoarseField(Xc, nvec, prec).set_logical(p) for p in phis]
+    Vt = int(np.prod(X))
+    loop = torch.zeros(16 * Vt, dtype=torch.complex128 if lprec == 8 else torch.complex64, device="cuda")
+    hip.prolongateContractBatched(loop, cf, sg, T)
+    ref = np.zeros(16 * Vt, dtype=np.complex128)
+    for n in range(nev):
+        psi = orc.prolongate(phis[n].astype(np.complex128), V.astype(np.complex128), X, bs)
+        orc.loop_contract(ref, psi, psi, float(np.float32(sg[n])) if prec == 4 else sg[n])
+    tol = 1e-12 if prec == 8 else (1e-5 if lprec == 4 else 1e-12)
+    assert rel_err(loop.cpu().numpy(), ref) < tol
+    # and it equals prolongate-then-contract through the separate operators
+    ff = [hip.SpinorField(X, prec, 2) for _ in range(nev)]
+    hip.prolongateEvecs(ff, cf, T)
+    loop2 = torch.zeros_like(loop)
+    hip.performLoopContractionBatched(loop2, ff, ff, sg)
+    assert rel_err(loop.cpu().numpy(), loop2.cpu().numpy()) < (1e-12 if lprec == 8 and prec == 8 else 1e-5)

@@ -322,3 +322,48 @@ def test_c_oracle_matches_numpy_oracle(order, dtype):
     c_oracle.loop_contract_native(got, bl, br, sg, V // 2, stride, 12 * stride, order)
     assert rel_err(got, ref) < (1e-15 if dtype == np.complex128 else 1e-6)
     assert c_oracle.num_threads() >= 1
+
+
+# ---- f2: prolongator -----------------------------------------------------------------------------------------
+def test_prolongator_block_structure_and_adjoint_identity():
+    """P is block-local and chirality-preserving; with block-orthonormal null vectors P^dag P = 1 on the coarse space."""
+    X, bs, nvec = (8, 4, 4, 8), (4, 2, 2, 4), 6
+    Xc = [X[d] // bs[d] for d in range(4)]
+    rng = np.random.default_rng(12)
+    vcb, vcbc = int(np.prod(X)) // 2, int(np.prod(Xc)) // 2
+    V = rng.standard_normal((2, vcb, 4, 3, nvec)) + 1j * rng.standard_normal((2, vcb, 4, 3, nvec))
+    cp, cx = orc.fine_to_coarse_map(X, bs)
+    # every coarse site owns prod(bs) fine sites, and the map agrees with coordinates
+    counts = np.zeros((2, vcbc), dtype=int)
+    np.add.at(counts, (cp.reshape(-1), cx.reshape(-1)), 1)
+    assert np.all(counts == int(np.prod(bs)))
+    # block-orthonormalise V per (aggregate, chirality): QR over the rows (fine site in block, spin in chirality, colour)
+    for p in range(2):
+        for xc in range(vcbc):
+            for chi in range(2):
+                rows = [(q, i) for q in range(2) for i in np.nonzero((cp[q] == p) & (cx[q] == xc))[0]]
+                M = np.concatenate([V[q, i, 2 * chi:2 * chi + 2].reshape(6, nvec) for q, i in rows])
+                Q, _ = np.linalg.qr(M)
+                for r, (q, i) in enumerate(rows):
+                    V[q, i, 2 * chi:2 * chi + 2] = Q[6 * r:6 * r + 6].reshape(2, 3, nvec)
+    phi = rng.standard_normal((2, vcbc, 2, nvec)) + 1j * rng.standard_normal((2, vcbc, 2, nvec))
+    psi = orc.prolongate(phi, V, X, bs)
+    assert abs(np.linalg.norm(psi) - np.linalg.norm(phi)) < 1e-12 * np.linalg.norm(phi)
+    # restrict back: R = P^dag
+    back = np.zeros_like(phi)
+    for pty in range(2):
+        for s in range(4):
+            contrib = np.einsum("xcj,xc->xj", V[pty, :, s].conj(), psi[pty, :, s])
+            np.add.at(back, (cp[pty], cx[pty], s // 2), contrib)
+    assert rel_err(back, phi) < 1e-12
+    # a coarse vector supported on one aggregate / chirality prolongs to that aggregate's sites and those spins only
+    one = np.zeros_like(phi)
+    one[1, 3, 1, 2] = 1.0
+    p1 = orc.prolongate(one, V, X, bs)
+    support = (np.abs(p1).sum(axis=(2, 3)) > 0)
+    assert np.array_equal(support, (cp == 1) & (cx == 3)) and np.all(p1[:, :, :2] == 0)
+    # native layouts round-trip through the index formulas
+    buf = orc.coarse_to_native(phi)
+    assert buf[1 * (2 * nvec * vcbc) + (1 * nvec + 2) * vcbc + 3] == phi[1, 3, 1, 2]
+    vb = orc.nullvec_to_native(V)
+    assert vb[0 * (12 * nvec * vcb) + ((3 * 2 + 1) * nvec + 4) * vcb + 5] == V[0, 5, 2, 1, 4]
