@@ -32,6 +32,7 @@ template <typename A> struct ContractArgs {
   int volumeCB;
   int stride;
   int64_t parity_offset;
+  int xcdSwizzle;          // 1: workgroups of one XCD (blockIdx % 8) cover one contiguous eighth of the sites
 };
 
 // streaming load of one site's 12 complex; NT = non-temporal (the eigenvectors are read exactly once)
@@ -62,7 +63,12 @@ __device__ inline void load_spinor(Cplx<A> v[12], const void *body, int64_t pari
 template <typename F, typename A, int ORDER, bool SAME, int BLOCK, int DEPTH, bool NT>
 __global__ __launch_bounds__(BLOCK) void loop_contract_kernel(ContractArgs<A> a) {
   const int V = 2 * a.volumeCB;
-  const int site = blockIdx.x * BLOCK + threadIdx.x;  // tid = x_cb + parity*volumeCB  (:52)
+  int blk = blockIdx.x;
+  if (a.xcdSwizzle) {  // dispatch deals workgroups round-robin over the 8 XCDs: give each XCD a contiguous site range
+    const int per = gridDim.x >> 3;
+    blk = (blk & 7) * per + (blk >> 3);
+  }
+  const int site = blk * BLOCK + threadIdx.x;  // tid = x_cb + parity*volumeCB  (:52)
   if (site >= V) return;
   const int parity = site >= a.volumeCB ? 1 : 0;
   const int x_cb = site - parity * a.volumeCB;
@@ -131,18 +137,19 @@ __global__ __launch_bounds__(BLOCK) void loop_contract_kernel(ContractArgs<A> a)
 // Launch configuration.  Defaults were picked by sweeping on MI355X (profiles/); MUGIQ_HIP_CONTRACT_TUNE="block,depth,nt"
 // overrides them for experiments (e.g. "512,3,1").
 struct ContractTune {
-  int block, depth, nt;
+  int block, depth, nt, swz;
 };
 static ContractTune contract_tune(bool same) {
   // sweep on MI355X, 32^4 x 200 fp64 (profiles/r01_contract_sweep.txt): non-temporal loads +4 %; block size and prefetch
   // depth within 1 % of each other (4-6 waves/SIMD already cover the latency), so the leanest variant is the default
-  ContractTune t{256, 1, 1};
+  ContractTune t{256, 1, 1, 1};
   if (const char *e = getenv("MUGIQ_HIP_CONTRACT_TUNE")) {
-    int b = 0, d = 0, n = 0;
-    if (sscanf(e, "%d,%d,%d", &b, &d, &n) == 3 && (b == 64 || b == 128 || b == 256 || b == 512) && d >= 1 && d <= 3 && (n == 0 || n == 1)) {
+    int b = 0, d = 0, n = 0, w = 0;
+    if (sscanf(e, "%d,%d,%d,%d", &b, &d, &n, &w) >= 3 && (b == 64 || b == 128 || b == 256 || b == 512) && d >= 1 && d <= 3 && (n == 0 || n == 1)) {
       t.block = b;
       t.depth = (!same && d > 2) ? 2 : d;
       t.nt = n;
+      t.swz = w ? 1 : 0;
     }
   }
   return t;
@@ -206,6 +213,7 @@ static int launch_contract(void *loop_d, const MugiqHipSpinorField *L, const Mug
   a.stride = L[0].stride;
   a.parity_offset = L[0].parity_offset;
   const ContractTune t = contract_tune(same);
+  a.xcdSwizzle = (t.swz && (((2 * a.volumeCB + t.block - 1) / t.block) % 8 == 0)) ? 1 : 0;
   if (same) launch_block<F, A, ORDER, true>(a, t, stream);
   else launch_block<F, A, ORDER, false>(a, t, stream);
   MUGIQ_CHECK_HIP(hipGetLastError());

@@ -24,13 +24,14 @@ ap.add_argument("--blocks", default="128,256,512")
 ap.add_argument("--depths", default="1,2,3")
 ap.add_argument("--nts", default="0,1")
 ap.add_argument("--pad", type=int, default=0)
+ap.add_argument("--swz", default="0")
 a = ap.parse_args()
 X = tuple(a.lattice)
 V = int(np.prod(X))
 big, fields = make_evecs(hip, X, a.nev, a.precision, a.order, torch.device("cuda"), 777, a.pad)
 sig = 0.01 + 0.002 * np.arange(a.nev)
 loop = torch.zeros(16 * V, dtype=torch.complex128 if a.precision == 8 else torch.complex64, device="cuda")
-variants = ["%s,%s,%s" % v for v in itertools.product(a.blocks.split(","), a.depths.split(","), a.nts.split(","))]
+variants = ["%s,%s,%s,%s" % v for v in itertools.product(a.blocks.split(","), a.depths.split(","), a.nts.split(","), a.swz.split(","))]
 times = {v: [] for v in variants}
 alg = V * (a.nev * 24 * a.precision + 32 * a.precision)
 for r in range(a.rounds + 1):
