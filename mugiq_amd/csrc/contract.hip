@@ -44,14 +44,14 @@ __device__ inline void load_spinor(Cplx<A> v[12], const void *body, int64_t pari
   if constexpr (ORDER == 2) {
 #pragma unroll
     for (int k = 0; k < 12; k++) {
-      const vec2 *q = reinterpret_cast<const vec2 *>(p + (int64_t)k * stride + x_cb);
+      const MUGIQ_GLOBAL vec2 *q = as_global(reinterpret_cast<const vec2 *>(p + (int64_t)k * stride + x_cb));
       vec2 t = NT ? __builtin_nontemporal_load(q) : *q;
       v[k] = Cplx<A>{(A)t.x, (A)t.y};
     }
   } else {
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      const vec4 *q = reinterpret_cast<const vec4 *>(p + ((int64_t)j * stride + x_cb) * 2);
+      const MUGIQ_GLOBAL vec4 *q = as_global(reinterpret_cast<const vec4 *>(p + ((int64_t)j * stride + x_cb) * 2));
       vec4 t = NT ? __builtin_nontemporal_load(q) : *q;
       v[2 * j] = Cplx<A>{(A)t.x, (A)t.y};
       v[2 * j + 1] = Cplx<A>{(A)t.z, (A)t.w};

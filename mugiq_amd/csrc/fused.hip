@@ -41,7 +41,13 @@ template <typename F, typename A> struct FusedArgs {
   const F *ghost;           // [nVec][layers][2][12][faceCB] in the eigenvectors' field order
   int64_t ghost_vec_stride; // complex elements per eigenvector = layers*24*faceCB
   int faceCB;
-  int xcdSwizzle;           // workgroups of one XCD cover one contiguous eighth of the sites
+  int xcdSwizzle;           // workgroups of one XCD cover one contiguous eighth of the (logical) workgroup order
+  // Displacement-aligned workgroup order (0 = off): consecutive workgroups of an XCD step along the displacement axis
+  // (and alternate parity), so v(x +- k mu) requested by one workgroup is the v(x) another one streams at about the
+  // same time: the shifted reads become L2 hits instead of HBM reads.  x_cb = hi*(J*strideMu) + j*strideMu + lo.
+  int remapJ;               // X[DIR]
+  int remapS;               // strideMu / 64
+  int strideMu;             // x_cb distance of one step along DIR = prod_{d<DIR} X[d] / 2
 };
 
 template <typename F, typename A, int ORDER, bool NT = false>
@@ -51,14 +57,14 @@ __device__ inline void load_lane(Cplx<A> v[12], const Cplx<F> *p, int64_t stride
   if constexpr (ORDER == 2) {
 #pragma unroll
     for (int k = 0; k < 12; k++) {
-      const vec2 *q = reinterpret_cast<const vec2 *>(p + k * stride + idx);
+      const MUGIQ_GLOBAL vec2 *q = as_global(reinterpret_cast<const vec2 *>(p + k * stride + idx));
       const vec2 t = NT ? __builtin_nontemporal_load(q) : *q;
       v[k] = Cplx<A>{(A)t.x, (A)t.y};
     }
   } else {
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      const vec4 *q = reinterpret_cast<const vec4 *>(p + (j * stride + idx) * 2);
+      const MUGIQ_GLOBAL vec4 *q = as_global(reinterpret_cast<const vec4 *>(p + (j * stride + idx) * 2));
       const vec4 t = NT ? __builtin_nontemporal_load(q) : *q;
       v[2 * j] = Cplx<A>{(A)t.x, (A)t.y};
       v[2 * j + 1] = Cplx<A>{(A)t.z, (A)t.w};
@@ -74,7 +80,18 @@ __global__ __launch_bounds__(64 * kFusedMaxSlots) void fused_displaced_contract_
     const int per = gridDim.x >> 3;
     blk = (blk & 7) * per + (blk >> 3);
   }
-  const int site = blk * 64 + threadIdx.x;
+  int site;
+  if (a.remapJ > 0) {
+    const int p = blk & 1;
+    int r = blk >> 1;
+    const int j = r % a.remapJ;
+    r /= a.remapJ;
+    const int c = r % a.remapS;
+    const int hi = r / a.remapS;
+    site = p * a.volumeCB + hi * (a.remapJ * a.strideMu) + j * a.strideMu + c * 64 + threadIdx.x;
+  } else {
+    site = blk * 64 + threadIdx.x;
+  }
   const int slot = threadIdx.y;
   if (site >= V) return;
   const int pty = site >= a.volumeCB ? 1 : 0;
@@ -212,9 +229,20 @@ template <typename F, typename A, int ORDER>
 static int launch_fused(FusedArgs<F, A> a, int dir, int sign, hipStream_t stream) {
   const int V = 2 * a.volumeCB;
   const dim3 grid((V + 63) / 64), block(64, a.nslot);
-  int nt = 1, swz = 1;  // measured on MI355X: together -6 % on 3 entries; MUGIQ_HIP_FUSED_TUNE = "nt,swizzle" overrides
-  if (const char *e = getenv("MUGIQ_HIP_FUSED_TUNE")) sscanf(e, "%d,%d", &nt, &swz);
+  int nt = 1, swz = 1, remap = 1;  // MUGIQ_HIP_FUSED_TUNE = "nt,swizzle,remap" overrides (profiles/r01_fused_tune.txt)
+  if (const char *e = getenv("MUGIQ_HIP_FUSED_TUNE")) sscanf(e, "%d,%d,%d", &nt, &swz, &remap);
   a.xcdSwizzle = (swz && grid.x % 8 == 0) ? 1 : 0;
+  long long strideMu = 1;
+  for (int d = 0; d < dir; d++) strideMu *= a.X[d];
+  strideMu /= 2;
+  a.remapJ = 0;
+  a.remapS = 0;
+  a.strideMu = (int)strideMu;
+  if (remap && dir >= 1 && strideMu % 64 == 0 && a.volumeCB % 64 == 0) {
+    a.remapJ = a.X[dir];
+    a.remapS = (int)(strideMu / 64);
+    nt = 0;  // the shifted reads are meant to hit in L2
+  }
 #define MUGIQ_FUSED_CASE(D, S)                                                                                     \
   case (D)*2 + (S):                                                                                                \
     if (nt) hipLaunchKernelGGL((fused_displaced_contract_kernel<F, A, ORDER, D, S, true>), grid, block, 0, stream, a);  \

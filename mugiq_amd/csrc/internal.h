@@ -31,6 +31,15 @@ int device_scratch(void **ptr, size_t bytes);
 // must be issued on one stream at a time per device (the reference's wrappers are not re-entrant either).
 int upload_table(void **dev, const void *host, size_t bytes, hipStream_t stream);
 
+// ---- address spaces ---------------------------------------------------------------------------------------------
+// Pointers fetched from a device-side table (eigenvector bodies) have no known address space, so hipcc emits
+// flat_load: those count on vmcnt AND lgkmcnt and return out of order, which forces one `s_waitcnt vmcnt(0)
+// lgkmcnt(0)` in front of the first use -- no load can overlap arithmetic inside a wave.  Casting to the global
+// address space turns them into global_load (ordered, counted waits).
+#define MUGIQ_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ inline const MUGIQ_GLOBAL T *as_global(const T *p) { return (const MUGIQ_GLOBAL T *)p; }
+template <typename T> __device__ inline MUGIQ_GLOBAL T *as_global(T *p) { return (MUGIQ_GLOBAL T *)p; }
+
 // ---- complex arithmetic in registers -------------------------------------------------------------
 template <typename F> struct alignas(2 * sizeof(F)) Cplx {
   F re, im;
