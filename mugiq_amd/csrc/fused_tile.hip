@@ -1,0 +1,316 @@
+// LDS-tiled fused displaced contraction (second generation of csrc/fused.hip, same mathematics and same C entry point).
+//
+// Measured on MI355X (profiles/r01_fused_*): the first-generation kernel streams v_n(x) and v_n(x +- k mu) for every slot
+// k from HBM/fabric -- 1 + nslots "units" of 24*B bytes per site and eigenvector -- and sits at the ~6 TB/s fabric limit
+// with no cache reuse (L2 turns over in ~5 us; the shifted data is requested by other workgroups microseconds apart).
+// But v_n(x + k mu) IS v_n at another site of the same straight line along mu.  Here a workgroup owns 64 such lines
+// ("columns": fixed other coordinates, consecutive coordinate j along mu, parity alternating with j) and TJ consecutive
+// positions on them.  Per eigenvector it stages the TJ + Kmax positions it needs in LDS once ([position][12][64 lanes],
+// one plane per wave, coalesced over the lines), and every (position, slot) pair -- one wave each -- reads both its
+// v_n(x) and its shifted v_n(x +- k mu) from LDS.  Global traffic drops from 1 + nslots to (TJ + Kmax)/TJ units per
+// site and eigenvector (TJ = 4, 3 slots: 4 -> 1.75).  The next eigenvector's global loads are in flight while the
+// current one is consumed (register double buffer, two barriers per eigenvector).
+// Positions beyond the local extent come from the ghost layers (partitioned) or wrap around (periodic), exactly as in
+// the first-generation kernel.  Requirements: DIR >= 1 (along x the line runs inside the coalescing direction; that
+// case keeps the first-generation kernel), X[DIR] % TJ == 0, at most 3 slots per launch.
+#include "internal.h"
+
+#include <cstdlib>
+#include <vector>
+
+namespace mugiq {
+
+constexpr int kTileTJ = 4;        // positions along mu per workgroup
+constexpr int kTileMaxSlots = 3;  // waves = kTileTJ * nslot <= 12
+constexpr int kTileMaxPos = 16;   // TJ + Kmax upper bound
+constexpr int kTileCols = 32;     // lines per workgroup (each line is held by two lanes: one per spin half)
+
+template <typename F, typename A> struct TileArgs {
+  Cplx<A> *loop;
+  int64_t slot_stride;
+  const void *const *L;
+  const A *inv_sigma;
+  int nVec;
+  int X[4];
+  int volumeCB;
+  int stride;
+  int64_t parity_offset;
+  const F *E[kTileMaxSlots];
+  int k[kTileMaxSlots];
+  int nslot;
+  int kmax;
+  int partitioned;
+  const F *ghost;
+  int64_t ghost_vec_stride;
+  int faceCB;
+  int strideMu;   // x_cb distance of one step along DIR
+  int H;          // volumeCB / (X[DIR] * strideMu)
+  int numCols;    // V / X[DIR]
+  int nJT;        // X[DIR] / TJ
+  int tileBytes;  // LDS bytes of the staging tile (W follows it)
+};
+
+// complex-element offset of component `comp` at checkerboard index idx inside one parity block of a field / ghost zone
+template <int ORDER> __device__ inline int64_t comp_offset(int comp, int64_t stride, int64_t idx) {
+  if constexpr (ORDER == 2) return (int64_t)comp * stride + idx;
+  else return ((int64_t)(comp >> 1) * stride + idx) * 2 + (comp & 1);
+}
+
+// Workgroup = 12 waves over 32 lines.  Wave w <-> (position jj = w % TJ, slot = w / TJ); inside a wave lanes 0-31 and
+// 32-63 hold the SAME 32 lines and split the right-hand spin index (al in {0,1} | {2,3}), so a lane carries 8 of the 16
+// accumulators -- at three waves per SIMD a lane has ~168 VGPRs, which 16 fp64 accumulators + W + the prefetch
+// registers do not fit into.  For staging, wave w owns plane w (component 3*spin + colour): its two lane halves fetch
+// alternate positions (32 lanes x 16 B = one 512-byte run each).  PH bounds the positions staged per lane.
+template <typename F, typename A, int ORDER, int DIR, int SIGN, int PH>
+__global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileArgs<F, A> a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  Cplx<F> *tile = reinterpret_cast<Cplx<F> *>(smem);  // [NP][12][32]
+  const int lane = threadIdx.x & 63;
+  const int col = lane & 31, half = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  const bool computes = wave < kTileTJ * a.nslot;
+  const int NP = kTileTJ + a.kmax;
+  const int J = a.X[DIR];
+
+  const int jt = blockIdx.x % a.nJT;
+  const int cc = blockIdx.x / a.nJT;
+  const int j0 = jt * kTileTJ;
+  const int cid = cc * kTileCols + col;
+  const bool active = cid < a.numCols;
+  // ---- the line this lane works on
+  const int colsPerParity = a.H * a.strideMu;
+  int p0 = 0, hi = 0, lo = 0;
+  if (active) {
+    p0 = cid / colsPerParity;
+    const int rem = cid - p0 * colsPerParity;
+    hi = rem / a.strideMu;
+    lo = rem - hi * a.strideMu;
+  }
+  const int base = hi * (J * a.strideMu) + lo;  // x_cb of the line's j = 0 site (parity p0)
+  int c0[4];
+  get_coords(c0, base, a.X, p0);                // c0[DIR] == 0
+  const int faceIdx = ghost_face_index_on_face(c0, a.X, DIR);
+  const Cplx<F> *ghostBase = reinterpret_cast<const Cplx<F> *>(a.ghost);
+
+  // ---- my (position, slot): position pp <-> coordinate j = j0 + pp (sign +) | j0 - kmax + pp (sign -)
+  const int jj = wave % kTileTJ;
+  const int slot = wave / kTileTJ;
+  const int k = a.k[slot];
+  const int ppL = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? jj : a.kmax + jj;
+  const int ppS = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? jj + k : a.kmax + jj - k;
+  const int jmine = j0 + jj;
+  const int pmine = p0 ^ (jmine & 1);
+  const int xmine = base + jmine * a.strideMu;
+
+  // W_k(x) of this wave's (position, slot) for the 32 lines lives in LDS behind the tile ([9][32] per wave, read by both
+  // lane halves): registers are the scarce resource here, LDS bandwidth is not
+  Cplx<A> *Wl = reinterpret_cast<Cplx<A> *>(smem + a.tileBytes) + wave * 9 * kTileCols + col;
+  if (active && half == 0) {
+    const Cplx<F> *e = reinterpret_cast<const Cplx<F> *>(a.E[slot]) + (int64_t)pmine * 12 * a.volumeCB + xmine;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const Cplx<F> t = e[(int64_t)(j * 3 + i) * a.volumeCB];
+        Wl[(i * 3 + j) * kTileCols] = Cplx<A>{(A)t.re, (A)t.im};
+      }
+  }
+  Cplx<A> acc[8];  // acc[be*2 + a2], al = 2*half + a2
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc[i] = Cplx<A>{A(0), A(0)};
+
+  typedef F vec2 __attribute__((ext_vector_type(2)));
+  vec2 stageA[PH], stageB[PH];  // two eigenvectors in flight ahead of the one being consumed
+  // fetch this lane's share of eigenvector n_: plane `wave`, line `col`, positions pp = 2*i + half
+#define MUGIQ_TILE_FETCH(n_, stage)                                                                                         \
+  {                                                                                                                    \
+    const Cplx<F> *body_ = static_cast<const Cplx<F> *>(a.L[n_]);                                                      \
+    const Cplx<F> *gh_ = ghostBase + (int64_t)(n_)*a.ghost_vec_stride;                                                 \
+    _Pragma("unroll") for (int i = 0; i < PH; i++) {                                                                   \
+      const int pp = 2 * i + half;                                                                                     \
+      if (pp < NP && active) {                                                                                         \
+        int j = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? j0 + pp : j0 - a.kmax + pp;                                       \
+        const int par = p0 ^ (j & 1);                                                                                  \
+        const Cplx<F> *ptr_;                                                                                           \
+        if ((j < 0 || j >= J) && a.partitioned) {                                                                      \
+          const int layer = (j >= J) ? j - J : -j - 1;                                                                 \
+          ptr_ = gh_ + (int64_t)layer * 24 * a.faceCB + (int64_t)par * 12 * a.faceCB + comp_offset<ORDER>(wave, a.faceCB, faceIdx); \
+        } else {                                                                                                       \
+          j = j < 0 ? j + J : (j >= J ? j - J : j);                                                                    \
+          ptr_ = body_ + (int64_t)par * a.parity_offset + comp_offset<ORDER>(wave, a.stride, base + j * a.strideMu);   \
+        }                                                                                                              \
+        stage[i] = *as_global(reinterpret_cast<const vec2 *>(ptr_));                                                   \
+      }                                                                                                                \
+    }                                                                                                                  \
+  }
+
+#define MUGIQ_TILE_STEP(n_, stage)                                                                                     \
+  {                                                                                                                    \
+    __syncthreads(); /* everyone is done reading the previous eigenvector from LDS */                                  \
+    _Pragma("unroll") for (int i = 0; i < PH; i++) {                                                                   \
+      const int pp = 2 * i + half;                                                                                     \
+      if (pp < NP) tile[(pp * 12 + wave) * kTileCols + col] = Cplx<F>{stage[i].x, stage[i].y};                         \
+    }                                                                                                                  \
+    __syncthreads();                                                                                                   \
+    if ((n_) + 2 < a.nVec) MUGIQ_TILE_FETCH((n_) + 2, stage) /* in flight while eigenvectors n_ and n_+1 are consumed */ \
+    if (computes) {                                                                                                    \
+      const A s = a.inv_sigma[n_];                                                                                     \
+      const Cplx<F> *tl = tile + (ppL * 12) * kTileCols + col;                                                         \
+      const Cplx<F> *ts = tile + (ppS * 12 + half * 6) * kTileCols + col; /* spins 2*half, 2*half + 1 */               \
+      /* t[a2] = s * W * psi[2*half + a2]: each W element and each psi element is read from LDS once */               \
+      Cplx<A> t0[3], t1[3];                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < 3; i++) t0[i] = t1[i] = Cplx<A>{A(0), A(0)};                               \
+      _Pragma("unroll") for (int j = 0; j < 3; j++) {                                                                  \
+        const Cplx<F> w0 = ts[j * kTileCols], w1 = ts[(3 + j) * kTileCols];                                            \
+        const Cplx<A> p0j{(A)w0.re, (A)w0.im}, p1j{(A)w1.re, (A)w1.im};                                                \
+        _Pragma("unroll") for (int i = 0; i < 3; i++) {                                                                \
+          const Cplx<A> w = Wl[(i * 3 + j) * kTileCols];                                                               \
+          cmadd(t0[i], w, p0j);                                                                                        \
+          cmadd(t1[i], w, p1j);                                                                                        \
+        }                                                                                                              \
+      }                                                                                                                \
+      _Pragma("unroll") for (int i = 0; i < 3; i++) {                                                                  \
+        t0[i] = Cplx<A>{s * t0[i].re, s * t0[i].im};                                                                   \
+        t1[i] = Cplx<A>{s * t1[i].re, s * t1[i].im};                                                                   \
+      }                                                                                                                \
+      _Pragma("unroll") for (int be = 0; be < 4; be++) {                                                               \
+        if (be == 2) __builtin_amdgcn_sched_barrier(0); /* bound how many LDS reads the scheduler hoists (VGPRs) */    \
+        _Pragma("unroll") for (int c = 0; c < 3; c++) {                                                                \
+          const Cplx<F> u = tl[(be * 3 + c) * kTileCols];                                                              \
+          const Cplx<A> lv{(A)u.re, (A)u.im};                                                                          \
+          cmadd_conj(acc[be * 2 + 0], lv, t0[c]);                                                                      \
+          cmadd_conj(acc[be * 2 + 1], lv, t1[c]);                                                                      \
+        }                                                                                                              \
+      }                                                                                                                \
+    }                                                                                                                  \
+  }
+
+  MUGIQ_TILE_FETCH(0, stageA)
+  if (a.nVec > 1) MUGIQ_TILE_FETCH(1, stageB)
+  for (int n = 0; n < a.nVec; n += 2) {
+    MUGIQ_TILE_STEP(n, stageA)
+    if (n + 1 < a.nVec) MUGIQ_TILE_STEP(n + 1, stageB)
+  }
+#undef MUGIQ_TILE_STEP
+  // ---- combine the two spin halves of every line, then the 16 gamma traces (lanes 0-31)
+  __syncthreads();
+  Cplx<A> *red = reinterpret_cast<Cplx<A> *>(smem);  // [12 waves][8][64 lanes]
+#pragma unroll
+  for (int i = 0; i < 8; i++) red[(wave * 8 + i) * 64 + lane] = acc[i];
+  __syncthreads();
+  if (active && computes && half == 0) {
+    Cplx<A> full[16];
+#pragma unroll
+    for (int be = 0; be < 4; be++)
+#pragma unroll
+      for (int al = 0; al < 4; al++) full[be * 4 + al] = red[(wave * 8 + be * 2 + (al & 1)) * 64 + col + 32 * (al >> 1)];
+    trace_and_store(a.loop + (int64_t)slot * a.slot_stride, full, 2 * a.volumeCB, xmine + pmine * a.volumeCB);
+  }
+}
+
+#undef MUGIQ_TILE_FETCH
+
+template <typename F, typename A, int ORDER> static int launch_tile(TileArgs<F, A> a, int dir, int sign, hipStream_t stream) {
+  const int NP = kTileTJ + a.kmax;
+  const size_t tileBytes = sizeof(Cplx<F>) * (size_t)NP * 12 * kTileCols;
+  size_t shmem = tileBytes + sizeof(Cplx<A>) * 12 * 9 * kTileCols;  // tile + W
+  const size_t redBytes = sizeof(Cplx<A>) * 12 * 8 * 64;            // epilogue exchange of the two spin halves
+  if (shmem < redBytes) shmem = redBytes;
+  a.tileBytes = (int)tileBytes;
+  const dim3 grid(((a.numCols + kTileCols - 1) / kTileCols) * a.nJT), block(64 * 12);
+#define MUGIQ_TILE_LAUNCH(D, S, P)                                                                                    \
+  {                                                                                                                   \
+    auto kern = tile_displaced_contract_kernel<F, A, ORDER, D, S, P>;                                                 \
+    if (shmem > 64 * 1024)                                                                                            \
+      MUGIQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+    hipLaunchKernelGGL(kern, grid, block, shmem, stream, a);                                                          \
+  }
+#define MUGIQ_TILE_CASE(D, S)                                                                                         \
+  case (D)*2 + (S):                                                                                                   \
+    if (NP <= 8) MUGIQ_TILE_LAUNCH(D, S, 4) else MUGIQ_TILE_LAUNCH(D, S, kTileMaxPos / 2)                             \
+    break;
+  switch (dir * 2 + sign) {
+    MUGIQ_TILE_CASE(1, 0) MUGIQ_TILE_CASE(1, 1) MUGIQ_TILE_CASE(2, 0) MUGIQ_TILE_CASE(2, 1) MUGIQ_TILE_CASE(3, 0) MUGIQ_TILE_CASE(3, 1)
+  default: return set_error(MUGIQ_HIP_ERROR_UNSUPPORTED, "tile kernel: direction x is not tiled");
+  }
+#undef MUGIQ_TILE_CASE
+#undef MUGIQ_TILE_LAUNCH
+  MUGIQ_CHECK_HIP(hipGetLastError());
+  return MUGIQ_HIP_SUCCESS;
+}
+
+// Can the tiled kernel take this entry?  (otherwise the caller uses the first-generation kernel)
+bool tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int precision) {
+  if (const char *e = getenv("MUGIQ_HIP_FUSED_TILE"))
+    if (atoi(e) == 0) return false;
+  if (dir < 1) return false;
+  if (ev.X[dir] % kTileTJ != 0) return false;
+  if (kTileTJ + kmax > kTileMaxPos) return false;
+  return true;
+}
+
+template <typename F, typename A, int ORDER>
+int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d, const int *kvals,
+               int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, hipStream_t stream) {
+  const size_t ptr_bytes = sizeof(void *) * (size_t)nVec;
+  std::vector<unsigned char> host(ptr_bytes + sizeof(A) * (size_t)nVec);
+  const void **hl = reinterpret_cast<const void **>(host.data());
+  A *hs = reinterpret_cast<A *>(host.data() + ptr_bytes);
+  for (int n = 0; n < nVec; n++) {
+    hl[n] = ev[n].data;
+    const F sg = static_cast<F>(sigma[n]);
+    hs[n] = static_cast<A>(1.0 / sg);
+  }
+  void *dev = nullptr;
+  int st = upload_table(&dev, host.data(), host.size(), stream);
+  if (st) return st;
+  TileArgs<F, A> a;
+  a.slot_stride = (int64_t)16 * 2 * ev[0].volumeCB;
+  a.L = reinterpret_cast<const void *const *>(dev);
+  a.inv_sigma = reinterpret_cast<const A *>(static_cast<unsigned char *>(dev) + ptr_bytes);
+  a.nVec = nVec;
+  long long strideMu = 1;
+  for (int d = 0; d < 4; d++) {
+    a.X[d] = ev[0].X[d];
+    if (d < dir) strideMu *= ev[0].X[d];
+  }
+  strideMu /= 2;
+  a.volumeCB = ev[0].volumeCB;
+  a.stride = ev[0].stride;
+  a.parity_offset = ev[0].parity_offset;
+  a.partitioned = partitioned;
+  a.ghost = static_cast<const F *>(ghost_d);
+  a.faceCB = ev[0].volumeCB / ev[0].X[dir];
+  a.ghost_vec_stride = (int64_t)layers * 24 * a.faceCB;
+  a.strideMu = (int)strideMu;
+  a.H = (int)(ev[0].volumeCB / (ev[0].X[dir] * strideMu));
+  a.numCols = 2 * ev[0].volumeCB / ev[0].X[dir];
+  a.nJT = ev[0].X[dir] / kTileTJ;
+  for (int k0 = 0; k0 < nK; k0 += kTileMaxSlots) {
+    a.nslot = (nK - k0 < kTileMaxSlots) ? nK - k0 : kTileMaxSlots;
+    a.loop = static_cast<Cplx<A> *>(loop_d) + (int64_t)k0 * a.slot_stride;
+    a.kmax = 0;
+    for (int s = 0; s < kTileMaxSlots; s++) {
+      const int i = k0 + (s < a.nslot ? s : 0);
+      a.E[s] = static_cast<const F *>(E_d[i]);
+      a.k[s] = kvals[i];
+      if (s < a.nslot && kvals[i] > a.kmax) a.kmax = kvals[i];
+    }
+    st = launch_tile<F, A, ORDER>(a, dir, sign, stream);
+    if (st) return st;
+  }
+  return MUGIQ_HIP_SUCCESS;
+}
+
+#define MUGIQ_TILE_INST(F, A, O)                                                                                                 \
+  template int tile_entry<F, A, O>(void *, const MugiqHipSpinorField *, const double *, int, const void *const *, const int *, int, \
+                                   int, int, int, const void *, int, hipStream_t);
+MUGIQ_TILE_INST(double, double, 2)
+MUGIQ_TILE_INST(double, double, 4)
+MUGIQ_TILE_INST(float, float, 2)
+MUGIQ_TILE_INST(float, float, 4)
+MUGIQ_TILE_INST(float, double, 2)
+MUGIQ_TILE_INST(float, double, 4)
+#undef MUGIQ_TILE_INST
+
+}  // namespace mugiq

@@ -256,3 +256,22 @@ def test_driver_mg_coarse_path(hip, calc, entries):
                                             orc.phase_matrix(moms, locV3, -1, X, X), X[3], cprm.nData, locV3, len(moms))
     assert rel_err(loop.dataMom_bcast, ref_mom) < 1e-12
     loop.close()
+
+
+@pytest.mark.parametrize("tile", ["0", "1"])
+def test_fused_plans_agree_tiled_and_streaming(hip, tile, monkeypatch):
+    """The LDS-tiled column kernel (csrc/fused_tile.hip) and the first-generation streaming kernel are two
+    implementations of the same entry point: both must match the oracle (y, z, t use the tile when enabled)."""
+    monkeypatch.setenv("MUGIQ_HIP_FUSED_TILE", tile)
+    X = (4, 8, 4, 8)
+    nev = 3
+    ev, Uo, f, U = _setup(hip, X, nev, 8, 2, 4242)
+    sg = sigmas(nev)
+    entry = "+y:1,3;-y:2,3;+z:1,2;-z:1;+t:1,3;-t:1,3;+x:1,2;+t:5,6"
+    prm = hip.MugiqLoopParam(gauge=U).set_displace_entry_string(entry)
+    loop = hip.Loop_Mugiq(prm, f, sg)
+    loop.computeCoarseLoop()
+    _, s, a, b = orc.parse_disp_entry_string(entry)
+    ref = orc.compute_loop_position_space(ev, sg, orc.LoopComputeParam(s, a, b), Uo, X)
+    assert rel_err(loop.dataPos_d.cpu().numpy(), ref) < 1e-12
+    loop.close()
