@@ -64,7 +64,8 @@ template <int ORDER> __device__ inline int64_t comp_offset(int comp, int64_t str
 template <typename F, typename A, int ORDER, int DIR, int SIGN, int PH>
 __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileArgs<F, A> a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  Cplx<F> *tile = reinterpret_cast<Cplx<F> *>(smem);  // [NP][12][32]
+  Cplx<F> *tileBase = reinterpret_cast<Cplx<F> *>(smem);  // 2 x [NP][12][32] (double-buffered over the eigenvectors)
+  const size_t tileElems = (size_t)(kTileTJ + a.kmax) * 12 * kTileCols;
   const int lane = threadIdx.x & 63;
   const int col = lane & 31, half = lane >> 5;
   const int wave = threadIdx.x >> 6;
@@ -144,15 +145,20 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
     }                                                                                                                  \
   }
 
+// One step: eigenvector n_ is in LDS buffer n_ % 2; `stage` holds eigenvector n_+1 (fetched two steps ago).
+// Commit n_+1 into the other buffer (everyone finished reading it before the barrier that ended the previous step),
+// refill `stage` with n_+3, consume n_, one barrier.
 #define MUGIQ_TILE_STEP(n_, stage)                                                                                     \
   {                                                                                                                    \
-    __syncthreads(); /* everyone is done reading the previous eigenvector from LDS */                                  \
-    _Pragma("unroll") for (int i = 0; i < PH; i++) {                                                                   \
-      const int pp = 2 * i + half;                                                                                     \
-      if (pp < NP) tile[(pp * 12 + wave) * kTileCols + col] = Cplx<F>{stage[i].x, stage[i].y};                         \
+    const Cplx<F> *tile = tileBase + (size_t)((n_) & 1) * tileElems;                                                   \
+    if ((n_) + 1 < a.nVec) {                                                                                           \
+      Cplx<F> *nxt = tileBase + (size_t)(((n_) + 1) & 1) * tileElems;                                                  \
+      _Pragma("unroll") for (int i = 0; i < PH; i++) {                                                                 \
+        const int pp = 2 * i + half;                                                                                   \
+        if (pp < NP) nxt[(pp * 12 + wave) * kTileCols + col] = Cplx<F>{stage[i].x, stage[i].y};                        \
+      }                                                                                                                \
     }                                                                                                                  \
-    __syncthreads();                                                                                                   \
-    if ((n_) + 2 < a.nVec) MUGIQ_TILE_FETCH((n_) + 2, stage) /* in flight while eigenvectors n_ and n_+1 are consumed */ \
+    if ((n_) + 3 < a.nVec) MUGIQ_TILE_FETCH((n_) + 3, stage)                                                           \
     if (computes) {                                                                                                    \
       const A s = a.inv_sigma[n_];                                                                                     \
       const Cplx<F> *tl = tile + (ppL * 12) * kTileCols + col;                                                         \
@@ -183,10 +189,19 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
         }                                                                                                              \
       }                                                                                                                \
     }                                                                                                                  \
+    __syncthreads();                                                                                                   \
   }
 
-  MUGIQ_TILE_FETCH(0, stageA)
-  if (a.nVec > 1) MUGIQ_TILE_FETCH(1, stageB)
+  // prologue: eigenvector 0 -> LDS buffer 0; eigenvectors 1 and 2 in flight in stageA / stageB
+  MUGIQ_TILE_FETCH(0, stageB)
+#pragma unroll
+  for (int i = 0; i < PH; i++) {
+    const int pp = 2 * i + half;
+    if (pp < NP) tileBase[(pp * 12 + wave) * kTileCols + col] = Cplx<F>{stageB[i].x, stageB[i].y};
+  }
+  if (a.nVec > 1) MUGIQ_TILE_FETCH(1, stageA)
+  if (a.nVec > 2) MUGIQ_TILE_FETCH(2, stageB)
+  __syncthreads();
   for (int n = 0; n < a.nVec; n += 2) {
     MUGIQ_TILE_STEP(n, stageA)
     if (n + 1 < a.nVec) MUGIQ_TILE_STEP(n + 1, stageB)
@@ -212,8 +227,8 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
 
 template <typename F, typename A, int ORDER> static int launch_tile(TileArgs<F, A> a, int dir, int sign, hipStream_t stream) {
   const int NP = kTileTJ + a.kmax;
-  const size_t tileBytes = sizeof(Cplx<F>) * (size_t)NP * 12 * kTileCols;
-  size_t shmem = tileBytes + sizeof(Cplx<A>) * 12 * 9 * kTileCols;  // tile + W
+  const size_t tileBytes = 2 * sizeof(Cplx<F>) * (size_t)NP * 12 * kTileCols;  // two buffers
+  size_t shmem = tileBytes + sizeof(Cplx<A>) * 12 * 9 * kTileCols;           // tiles + W
   const size_t redBytes = sizeof(Cplx<A>) * 12 * 8 * 64;            // epilogue exchange of the two spin halves
   if (shmem < redBytes) shmem = redBytes;
   a.tileBytes = (int)tileBytes;
@@ -246,7 +261,8 @@ bool tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int preci
   if (dir < 1) return false;
   if (ev.X[dir] % kTileTJ != 0) return false;
   if (kTileTJ + kmax > kTileMaxPos) return false;
-  return true;
+  const size_t lds = (size_t)2 * 2 * precision * (kTileTJ + kmax) * 12 * kTileCols + (size_t)16 * 12 * 9 * kTileCols;
+  return lds <= 160 * 1024;
 }
 
 template <typename F, typename A, int ORDER>

@@ -21,6 +21,7 @@ ap.add_argument("--order", type=int, default=2)
 ap.add_argument("--entries", default="+x:1,3;-x:1,3;+y:1,3;-y:1,3;+z:1,3;-z:1,3;+t:1,3;-t:1,3")
 ap.add_argument("--plans", default="opt,basic")
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--ab-tile", action="store_true", help="alternate MUGIQ_HIP_FUSED_TILE=0/1 in one process (interleaved rounds)")
 a = ap.parse_args()
 
 X = tuple(a.lattice)
@@ -55,6 +56,24 @@ g.data.copy_(q.reshape(-1).to(cdt))
 sig = 0.01 + 0.002 * np.arange(a.nev)
 B = a.precision
 res = {}
+if a.ab_tile:
+    prm = hip.MugiqLoopParam(gauge=g, calcType=hip.LOOP_CALC_TYPE_OPT_KERNEL)
+    prm.set_displace_entry_string(a.entries)
+    loop = hip.Loop_Mugiq(prm, fields, sig)
+    ts = {"0": [], "1": []}
+    for r in range(a.reps + 1):
+        for t in ("0", "1"):
+            os.environ["MUGIQ_HIP_FUSED_TILE"] = t
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loop.computeCoarseLoop()
+            torch.cuda.synchronize()
+            if r > 0:
+                ts[t].append(time.perf_counter() - t0)
+    print(json.dumps({"lattice": X, "nev": a.nev, "entries": a.entries,
+                      "streaming_median_s": float(np.median(ts["0"])), "tiled_median_s": float(np.median(ts["1"])),
+                      "streaming_all": ts["0"], "tiled_all": ts["1"]}))
+    sys.exit(0)
 for plan in a.plans.split(","):
     prm = hip.MugiqLoopParam(gauge=g, calcType=hip.LOOP_CALC_TYPE_OPT_KERNEL if plan == "opt" else hip.LOOP_CALC_TYPE_BASIC_KERNEL)
     prm.set_displace_entry_string(a.entries)
