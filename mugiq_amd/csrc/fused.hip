@@ -258,7 +258,7 @@ static int launch_fused(FusedArgs<F, A> a, int dir, int sign, hipStream_t stream
 }
 
 // second-generation (LDS-tiled) kernel, csrc/fused_tile.hip
-bool tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int precision);
+bool tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int precision, int partitioned);
 template <typename F, typename A, int ORDER>
 int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d, const int *kvals,
                int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, hipStream_t stream);
@@ -270,7 +270,7 @@ static int fused_entry(void *loop_d, const MugiqHipSpinorField *ev, const double
   {
     int kmax = 0;
     for (int i = 0; i < nK; i++) kmax = kvals[i] > kmax ? kvals[i] : kmax;
-    if (tile_applicable(ev[0], dir, kmax, ev[0].precision))
+    if (tile_applicable(ev[0], dir, kmax, ev[0].precision, partitioned))
       return tile_entry<F, A, ORDER>(loop_d, ev, sigma, nVec, E_d, kvals, nK, dir, sign, partitioned, ghost_d, layers, stream);
   }
   const size_t ptr_bytes = sizeof(void *) * (size_t)nVec;

@@ -65,48 +65,104 @@ template <typename F, typename A, int ORDER, int DIR, int SIGN, int PH>
 __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileArgs<F, A> a) {
   extern __shared__ __align__(16) unsigned char smem[];
   Cplx<F> *tileBase = reinterpret_cast<Cplx<F> *>(smem);  // 2 x [NP][12][32] (double-buffered over the eigenvectors)
-  const size_t tileElems = (size_t)(kTileTJ + a.kmax) * 12 * kTileCols;
+  const size_t tileElems = (size_t)(2 * PH) * 12 * kTileCols;  // padded to 2*PH positions: commits are unconditional
   const int lane = threadIdx.x & 63;
   const int col = lane & 31, half = lane >> 5;
   const int wave = threadIdx.x >> 6;
   const bool computes = wave < kTileTJ * a.nslot;
-  const int NP = kTileTJ + a.kmax;
+  const int NP = (DIR >= 1) ? kTileTJ + a.kmax : kTileTJ;
   const int J = a.X[DIR];
 
-  const int jt = blockIdx.x % a.nJT;
-  const int cc = blockIdx.x / a.nJT;
-  const int j0 = jt * kTileTJ;
-  const int cid = cc * kTileCols + col;
-  const bool active = cid < a.numCols;
-  // ---- the line this lane works on
-  const int colsPerParity = a.H * a.strideMu;
-  int p0 = 0, hi = 0, lo = 0;
-  if (active) {
-    p0 = cid / colsPerParity;
-    const int rem = cid - p0 * colsPerParity;
-    hi = rem / a.strideMu;
-    lo = rem - hi * a.strideMu;
-  }
-  const int base = hi * (J * a.strideMu) + lo;  // x_cb of the line's j = 0 site (parity p0)
-  int c0[4];
-  get_coords(c0, base, a.X, p0);                // c0[DIR] == 0
-  const int faceIdx = ghost_face_index_on_face(c0, a.X, DIR);
-  const Cplx<F> *ghostBase = reinterpret_cast<const Cplx<F> *>(a.ghost);
-
-  // ---- my (position, slot): position pp <-> coordinate j = j0 + pp (sign +) | j0 - kmax + pp (sign -)
-  const int jj = wave % kTileTJ;
+  // ---- which sites this lane works on, and where every staged position lives
+  //  DIR >= 1 ("column" tile): 32 lines along mu x TJ consecutive positions j0..j0+TJ-1; position pp <-> coordinate
+  //            j = j0 + pp (sign +) | j0 - kmax + pp (sign -), parity alternating with j, x_cb = base + j*strideMu.
+  //  DIR == 0 ("row" tile): the lines run along x, i.e. along the coalescing direction, so the tile is 2 row groups
+  //            x 2 parities of whole x-rows (32 checkerboard entries each): position pp = parity | rowgroup << 1; a
+  //            shifted site is another entry of the same row in the other (k odd) or same (k even) parity -- every
+  //            eigenvector is read exactly once (1 unit).
+  const int wpos = wave % kTileTJ;  // this wave's own position index (jj for the column tile)
   const int slot = wave / kTileTJ;
   const int k = a.k[slot];
-  const int ppL = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? jj : a.kmax + jj;
-  const int ppS = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? jj + k : a.kmax + jj - k;
-  const int jmine = j0 + jj;
-  const int pmine = p0 ^ (jmine & 1);
-  const int xmine = base + jmine * a.strideMu;
+  int jt = 0, cc = blockIdx.x, j0 = 0;
+  bool active;
+  int p0 = 0, base = 0, faceIdx = 0;         // column tile
+  int ePR = 1, rowsPerGroup = 1;             // row tile
+  if constexpr (DIR >= 1) {
+    jt = blockIdx.x % a.nJT;
+    cc = blockIdx.x / a.nJT;
+    j0 = jt * kTileTJ;
+    int cid = cc * kTileCols + col;
+    active = cid < a.numCols;
+    if (!active) cid = a.numCols - 1;  // surplus lanes shadow the last line (valid addresses, result dropped)
+    const int colsPerParity = a.H * a.strideMu;
+    p0 = cid / colsPerParity;
+    const int rem = cid - p0 * colsPerParity;
+    const int hi = rem / a.strideMu;
+    const int lo = rem - hi * a.strideMu;
+    base = hi * (J * a.strideMu) + lo;  // x_cb of the line's j = 0 site (parity p0)
+    int c0[4];
+    get_coords(c0, base, a.X, p0);      // c0[DIR] == 0
+    faceIdx = ghost_face_index_on_face(c0, a.X, DIR);
+  } else {
+    ePR = a.X[0] >> 1;                  // checkerboard entries per x-row
+    rowsPerGroup = kTileCols / ePR;
+    active = col < rowsPerGroup * ePR;  // the host guarantees an even number of whole row groups
+  }
+  const Cplx<F> *ghostBase = reinterpret_cast<const Cplx<F> *>(a.ghost);
+  // x_cb of (row-tile position pp, this lane's column)
+  const int colClamped = active ? col : 0;
+  auto rowTileXcb = [&](int pp) { return ((2 * cc + (pp >> 1)) * rowsPerGroup) * ePR + colClamped; };
+
+  // source of every position this lane stages (fixed for the whole kernel): element offset + "is a ghost layer" bit
+  int soff[PH];
+  unsigned sghost = 0;
+#pragma unroll
+  for (int i = 0; i < PH; i++) {
+    const int pp = (2 * i + half < NP) ? 2 * i + half : NP - 1;  // surplus slots re-read the last position
+    soff[i] = 0;
+    {
+      if constexpr (DIR >= 1) {
+        int j = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? j0 + pp : j0 - a.kmax + pp;
+        const int par = p0 ^ (j & 1);
+        if ((j < 0 || j >= J) && a.partitioned) {
+          const int layer = (j >= J) ? j - J : -j - 1;
+          sghost |= 1u << i;
+          soff[i] = (int)((int64_t)layer * 24 * a.faceCB + (int64_t)par * 12 * a.faceCB + comp_offset<ORDER>(wave, a.faceCB, faceIdx));
+        } else {
+          j = j < 0 ? j + J : (j >= J ? j - J : j);
+          soff[i] = (int)((int64_t)par * a.parity_offset + comp_offset<ORDER>(wave, a.stride, base + j * a.strideMu));
+        }
+      } else {
+        soff[i] = (int)((int64_t)(pp & 1) * a.parity_offset + comp_offset<ORDER>(wave, a.stride, rowTileXcb(pp)));
+      }
+    }
+  }
+
+  // ---- my site, and the LDS slots of my v(x) and of my shifted v(x +- k mu)
+  int pmine, xmine, ppL, ppS, colS = col;
+  if constexpr (DIR >= 1) {
+    ppL = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? wpos : a.kmax + wpos;
+    ppS = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? wpos + k : a.kmax + wpos - k;
+    const int jmine = j0 + wpos;
+    pmine = p0 ^ (jmine & 1);
+    xmine = base + jmine * a.strideMu;
+  } else {
+    ppL = wpos;
+    pmine = wpos & 1;
+    xmine = rowTileXcb(wpos);
+    int c[4];
+    get_coords(c, xmine, a.X, pmine);
+    int xs = c[0] + ((SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? k : -k);
+    xs %= a.X[0];
+    if (xs < 0) xs += a.X[0];
+    ppS = (wpos ^ (k & 1));                       // parity flips for odd k, same row group
+    colS = (col / ePR) * ePR + (xs >> 1);        // same row, entry x0' / 2
+  }
 
   // W_k(x) of this wave's (position, slot) for the 32 lines lives in LDS behind the tile ([9][32] per wave, read by both
   // lane halves): registers are the scarce resource here, LDS bandwidth is not
   Cplx<A> *Wl = reinterpret_cast<Cplx<A> *>(smem + a.tileBytes) + wave * 9 * kTileCols + col;
-  if (active && half == 0) {
+  if (half == 0) {
     const Cplx<F> *e = reinterpret_cast<const Cplx<F> *>(a.E[slot]) + (int64_t)pmine * 12 * a.volumeCB + xmine;
 #pragma unroll
     for (int j = 0; j < 3; j++)
@@ -121,48 +177,45 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
   for (int i = 0; i < 8; i++) acc[i] = Cplx<A>{A(0), A(0)};
 
   typedef F vec2 __attribute__((ext_vector_type(2)));
-  vec2 stageA[PH], stageB[PH];  // two eigenvectors in flight ahead of the one being consumed
-  // fetch this lane's share of eigenvector n_: plane `wave`, line `col`, positions pp = 2*i + half
-#define MUGIQ_TILE_FETCH(n_, stage)                                                                                         \
+  vec2 stageA[PH], stageB[PH], stageC[PH];  // three eigenvectors in flight ahead of the one being consumed (latency!)
+  // fetch this lane's share of eigenvector n_: plane `wave`, column `col`, positions pp = 2*i + half
+#define MUGIQ_TILE_FETCH(n_, stage)                                                                                    \
   {                                                                                                                    \
     const Cplx<F> *body_ = static_cast<const Cplx<F> *>(a.L[n_]);                                                      \
     const Cplx<F> *gh_ = ghostBase + (int64_t)(n_)*a.ghost_vec_stride;                                                 \
-    _Pragma("unroll") for (int i = 0; i < PH; i++) {                                                                   \
-      const int pp = 2 * i + half;                                                                                     \
-      if (pp < NP && active) {                                                                                         \
-        int j = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? j0 + pp : j0 - a.kmax + pp;                                       \
-        const int par = p0 ^ (j & 1);                                                                                  \
-        const Cplx<F> *ptr_;                                                                                           \
-        if ((j < 0 || j >= J) && a.partitioned) {                                                                      \
-          const int layer = (j >= J) ? j - J : -j - 1;                                                                 \
-          ptr_ = gh_ + (int64_t)layer * 24 * a.faceCB + (int64_t)par * 12 * a.faceCB + comp_offset<ORDER>(wave, a.faceCB, faceIdx); \
-        } else {                                                                                                       \
-          j = j < 0 ? j + J : (j >= J ? j - J : j);                                                                    \
-          ptr_ = body_ + (int64_t)par * a.parity_offset + comp_offset<ORDER>(wave, a.stride, base + j * a.strideMu);   \
-        }                                                                                                              \
-        stage[i] = *as_global(reinterpret_cast<const vec2 *>(ptr_));                                                   \
-      }                                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < PH; i++) { /* unconditional: every lane and slot has a valid source */       \
+      const Cplx<F> *ptr_ = (((sghost >> i) & 1u) ? gh_ : body_) + soff[i];                                            \
+      stage[i] = *as_global(reinterpret_cast<const vec2 *>(ptr_));                                                     \
     }                                                                                                                  \
   }
 
-// One step: eigenvector n_ is in LDS buffer n_ % 2; `stage` holds eigenvector n_+1 (fetched two steps ago).
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() lowers to `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`,
+// i.e. it also drains every global load in flight -- which would serialise the register prefetch of the next
+// eigenvectors behind each barrier.  The stage registers are guarded by the compiler's own counted vmcnt waits.
+#define MUGIQ_LDS_BARRIER()                              \
+  {                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+    __builtin_amdgcn_s_barrier();                        \
+    asm volatile("" ::: "memory");                       \
+  }
+
+// One step: eigenvector n_ is in LDS buffer n_ % 2; `stage` holds eigenvector n_+1 (fetched three steps ago).
 // Commit n_+1 into the other buffer (everyone finished reading it before the barrier that ended the previous step),
-// refill `stage` with n_+3, consume n_, one barrier.
-#define MUGIQ_TILE_STEP(n_, stage)                                                                                     \
+// refill `stage` with n_+4, consume n_, one barrier.  (Little's law: with one workgroup per CU the bytes in flight
+// are what the stage registers hold -- 3 x 42 KB per CU sustains ~6 TB/s at ~4 us loaded latency, 2 x 42 KB does not.)
+#define MUGIQ_TILE_STEP(n_, stage, GUARD)                                                                              \
   {                                                                                                                    \
     const Cplx<F> *tile = tileBase + (size_t)((n_) & 1) * tileElems;                                                   \
-    if ((n_) + 1 < a.nVec) {                                                                                           \
+    if (GUARD == 0 || (n_) + 1 < a.nVec) {                                                                             \
       Cplx<F> *nxt = tileBase + (size_t)(((n_) + 1) & 1) * tileElems;                                                  \
-      _Pragma("unroll") for (int i = 0; i < PH; i++) {                                                                 \
-        const int pp = 2 * i + half;                                                                                   \
-        if (pp < NP) nxt[(pp * 12 + wave) * kTileCols + col] = Cplx<F>{stage[i].x, stage[i].y};                        \
-      }                                                                                                                \
+      _Pragma("unroll") for (int i = 0; i < PH; i++)                                                                   \
+        nxt[((2 * i + half) * 12 + wave) * kTileCols + col] = Cplx<F>{stage[i].x, stage[i].y};                         \
     }                                                                                                                  \
-    if ((n_) + 3 < a.nVec) MUGIQ_TILE_FETCH((n_) + 3, stage)                                                           \
+    if (GUARD == 0 || (n_) + 4 < a.nVec) MUGIQ_TILE_FETCH((n_) + 4, stage)                                             \
     if (computes) {                                                                                                    \
       const A s = a.inv_sigma[n_];                                                                                     \
       const Cplx<F> *tl = tile + (ppL * 12) * kTileCols + col;                                                         \
-      const Cplx<F> *ts = tile + (ppS * 12 + half * 6) * kTileCols + col; /* spins 2*half, 2*half + 1 */               \
+      const Cplx<F> *ts = tile + (ppS * 12 + half * 6) * kTileCols + colS; /* spins 2*half, 2*half + 1 */              \
       /* t[a2] = s * W * psi[2*half + a2]: each W element and each psi element is read from LDS once */               \
       Cplx<A> t0[3], t1[3];                                                                                            \
       _Pragma("unroll") for (int i = 0; i < 3; i++) t0[i] = t1[i] = Cplx<A>{A(0), A(0)};                               \
@@ -189,22 +242,29 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
         }                                                                                                              \
       }                                                                                                                \
     }                                                                                                                  \
-    __syncthreads();                                                                                                   \
+    MUGIQ_LDS_BARRIER()                                                                                                \
   }
 
-  // prologue: eigenvector 0 -> LDS buffer 0; eigenvectors 1 and 2 in flight in stageA / stageB
-  MUGIQ_TILE_FETCH(0, stageB)
+  // prologue: eigenvector 0 -> LDS buffer 0; eigenvectors 1, 2, 3 in flight in stageA / stageB / stageC
+  MUGIQ_TILE_FETCH(0, stageC)
 #pragma unroll
-  for (int i = 0; i < PH; i++) {
-    const int pp = 2 * i + half;
-    if (pp < NP) tileBase[(pp * 12 + wave) * kTileCols + col] = Cplx<F>{stageB[i].x, stageB[i].y};
-  }
+  for (int i = 0; i < PH; i++) tileBase[((2 * i + half) * 12 + wave) * kTileCols + col] = Cplx<F>{stageC[i].x, stageC[i].y};
   if (a.nVec > 1) MUGIQ_TILE_FETCH(1, stageA)
   if (a.nVec > 2) MUGIQ_TILE_FETCH(2, stageB)
-  __syncthreads();
-  for (int n = 0; n < a.nVec; n += 2) {
-    MUGIQ_TILE_STEP(n, stageA)
-    if (n + 1 < a.nVec) MUGIQ_TILE_STEP(n + 1, stageB)
+  if (a.nVec > 3) MUGIQ_TILE_FETCH(3, stageC)
+  MUGIQ_LDS_BARRIER()
+  // steady state without any data-dependent branch (hipcc's wait-count pass turns every conditional load into a
+  // conservative `vmcnt(0)`, which would serialise the prefetch), then a guarded tail
+  int n = 0;
+  for (; n + 6 < a.nVec; n += 3) {
+    MUGIQ_TILE_STEP(n, stageA, 0)
+    MUGIQ_TILE_STEP(n + 1, stageB, 0)
+    MUGIQ_TILE_STEP(n + 2, stageC, 0)
+  }
+  for (; n < a.nVec; n += 3) {
+    MUGIQ_TILE_STEP(n, stageA, 1)
+    if (n + 1 < a.nVec) MUGIQ_TILE_STEP(n + 1, stageB, 1)
+    if (n + 2 < a.nVec) MUGIQ_TILE_STEP(n + 2, stageC, 1)
   }
 #undef MUGIQ_TILE_STEP
   // ---- combine the two spin halves of every line, then the 16 gamma traces (lanes 0-31)
@@ -226,13 +286,19 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
 #undef MUGIQ_TILE_FETCH
 
 template <typename F, typename A, int ORDER> static int launch_tile(TileArgs<F, A> a, int dir, int sign, hipStream_t stream) {
-  const int NP = kTileTJ + a.kmax;
-  const size_t tileBytes = 2 * sizeof(Cplx<F>) * (size_t)NP * 12 * kTileCols;  // two buffers
+  const int NP = dir >= 1 ? kTileTJ + a.kmax : kTileTJ;
+  const int PHsel = NP <= 8 ? 4 : kTileMaxPos / 2;
+  const size_t tileBytes = 2 * sizeof(Cplx<F>) * (size_t)(2 * PHsel) * 12 * kTileCols;  // two buffers, padded positions
   size_t shmem = tileBytes + sizeof(Cplx<A>) * 12 * 9 * kTileCols;           // tiles + W
   const size_t redBytes = sizeof(Cplx<A>) * 12 * 8 * 64;            // epilogue exchange of the two spin halves
   if (shmem < redBytes) shmem = redBytes;
   a.tileBytes = (int)tileBytes;
-  const dim3 grid(((a.numCols + kTileCols - 1) / kTileCols) * a.nJT), block(64 * 12);
+  unsigned nblocks = ((a.numCols + kTileCols - 1) / kTileCols) * a.nJT;
+  if (dir == 0) {  // row tile: 2 groups of kTileCols/(X0/2) whole x-rows per workgroup
+    const int ePR = a.X[0] / 2, rpg = kTileCols / ePR;
+    nblocks = (unsigned)(a.volumeCB / ePR / rpg / 2);
+  }
+  const dim3 grid(nblocks), block(64 * 12);
 #define MUGIQ_TILE_LAUNCH(D, S, P)                                                                                    \
   {                                                                                                                   \
     auto kern = tile_displaced_contract_kernel<F, A, ORDER, D, S, P>;                                                 \
@@ -245,8 +311,8 @@ template <typename F, typename A, int ORDER> static int launch_tile(TileArgs<F, 
     if (NP <= 8) MUGIQ_TILE_LAUNCH(D, S, 4) else MUGIQ_TILE_LAUNCH(D, S, kTileMaxPos / 2)                             \
     break;
   switch (dir * 2 + sign) {
-    MUGIQ_TILE_CASE(1, 0) MUGIQ_TILE_CASE(1, 1) MUGIQ_TILE_CASE(2, 0) MUGIQ_TILE_CASE(2, 1) MUGIQ_TILE_CASE(3, 0) MUGIQ_TILE_CASE(3, 1)
-  default: return set_error(MUGIQ_HIP_ERROR_UNSUPPORTED, "tile kernel: direction x is not tiled");
+    MUGIQ_TILE_CASE(0, 0) MUGIQ_TILE_CASE(0, 1) MUGIQ_TILE_CASE(1, 0) MUGIQ_TILE_CASE(1, 1)
+    MUGIQ_TILE_CASE(2, 0) MUGIQ_TILE_CASE(2, 1) MUGIQ_TILE_CASE(3, 0) MUGIQ_TILE_CASE(3, 1)
   }
 #undef MUGIQ_TILE_CASE
 #undef MUGIQ_TILE_LAUNCH
@@ -254,14 +320,22 @@ template <typename F, typename A, int ORDER> static int launch_tile(TileArgs<F, 
   return MUGIQ_HIP_SUCCESS;
 }
 
-// Can the tiled kernel take this entry?  (otherwise the caller uses the first-generation kernel)
-bool tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int precision) {
-  if (const char *e = getenv("MUGIQ_HIP_FUSED_TILE"))
-    if (atoi(e) == 0) return false;
-  if (dir < 1) return false;
+// Can the tiled kernel take this entry?  (otherwise the caller uses the first-generation streaming kernel)
+bool tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int precision, int partitioned) {
+  int mode = 1;  // MUGIQ_HIP_FUSED_TILE: 0 = streaming kernel only, 2 = column tile only (no row tile), default both
+  if (const char *e = getenv("MUGIQ_HIP_FUSED_TILE")) mode = atoi(e);
+  if (mode == 0 || (mode == 2 && dir == 0)) return false;
+  if (dir == 0) {  // row tile: whole x-rows in LDS, no ghost handling
+    const int ePR = ev.X[0] / 2;
+    if (partitioned || ePR > kTileCols || kmax >= ev.X[0]) return false;
+    const int rpg = kTileCols / ePR;
+    if ((ev.volumeCB / ePR) % (2 * rpg) != 0) return false;
+    return true;
+  }
   if (ev.X[dir] % kTileTJ != 0) return false;
   if (kTileTJ + kmax > kTileMaxPos) return false;
-  const size_t lds = (size_t)2 * 2 * precision * (kTileTJ + kmax) * 12 * kTileCols + (size_t)16 * 12 * 9 * kTileCols;
+  const int PHsel = kTileTJ + kmax <= 8 ? 4 : kTileMaxPos / 2;
+  const size_t lds = (size_t)2 * 2 * precision * (2 * PHsel) * 12 * kTileCols + (size_t)16 * 12 * 9 * kTileCols;
   return lds <= 160 * 1024;
 }
 
@@ -298,6 +372,7 @@ int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma,
   a.ghost = static_cast<const F *>(ghost_d);
   a.faceCB = ev[0].volumeCB / ev[0].X[dir];
   a.ghost_vec_stride = (int64_t)layers * 24 * a.faceCB;
+  if (dir == 0) strideMu = 1;  // unused by the row tile (a step along x is half a checkerboard entry)
   a.strideMu = (int)strideMu;
   a.H = (int)(ev[0].volumeCB / (ev[0].X[dir] * strideMu));
   a.numCols = 2 * ev[0].volumeCB / ev[0].X[dir];

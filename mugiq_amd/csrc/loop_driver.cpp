@@ -74,7 +74,15 @@ struct MugiqHipLoop_s {
   MugiqHipTransfer transfer;
   void *fineStore = nullptr;  // prolonged eigenvectors, owned; NULL when only the fused prolong-contract is needed
   // ---- displacement scratch (Displace::auxDispVec and friends)
-  std::vector<void *> scratch;  // device allocations freed in the destructor
+  // Scratch lives in a pool owned by the loop object: hipMalloc/hipFree of ~GB buffers per displacement entry cost
+  // 10-100 ms and synchronise the device (measured), so buffers are recycled across entries and computes.
+  struct PoolBuf {
+    void *ptr;
+    size_t bytes;
+    bool inUse;
+  };
+  std::vector<PoolBuf> pool;
+  std::vector<void *> scratch;  // pool buffers handed out for the current entry (returned by free_scratch)
 
   size_t cplxBytes() const { return 2 * (size_t)precision; }      // eigenvector / link storage
   size_t loopBytes() const { return 2 * (size_t)loopPrecision; }  // loop buffers, phases, momentum projection
@@ -92,6 +100,24 @@ static int dev_alloc(MugiqHipLoop *lp, void **p, size_t bytes, bool zero) {
   return MUGIQ_HIP_SUCCESS;
 }
 
+// scratch from the loop's pool (best fit among the free buffers, else a new allocation); returned by free_scratch
+static int scratch_alloc(MugiqHipLoop *lp, void **p, size_t bytes, bool zero) {
+  int best = -1;
+  for (size_t i = 0; i < lp->pool.size(); i++)
+    if (!lp->pool[i].inUse && lp->pool[i].bytes >= bytes && (best < 0 || lp->pool[i].bytes < lp->pool[best].bytes)) best = (int)i;
+  if (best < 0) {
+    void *q = nullptr;
+    MUGIQ_CHECK_HIP(hipMalloc(&q, bytes ? bytes : 16));
+    lp->pool.push_back({q, bytes, false});
+    best = (int)lp->pool.size() - 1;
+  }
+  lp->pool[best].inUse = true;
+  *p = lp->pool[best].ptr;
+  lp->scratch.push_back(*p);
+  if (zero) MUGIQ_CHECK_HIP(hipMemsetAsync(*p, 0, bytes, lp->stream));
+  return MUGIQ_HIP_SUCCESS;
+}
+
 // A FLOAT2, pad-0 scratch field with the eigenvectors' geometry (+ room for both depth-1 ghost zones of `dim`).
 static int make_scratch_field(MugiqHipLoop *lp, MugiqHipSpinorField *f, int order) {
   *f = lp->eVecs[0];
@@ -100,9 +126,8 @@ static int make_scratch_field(MugiqHipLoop *lp, MugiqHipSpinorField *f, int orde
   f->parity_offset = (int64_t)12 * lp->volumeCB;
   for (int d = 0; d < 4; d++) f->ghost[d][0] = f->ghost[d][1] = nullptr;
   void *p = nullptr;
-  int st = dev_alloc(lp, &p, (size_t)2 * f->parity_offset * lp->cplxBytes(), true);
+  int st = scratch_alloc(lp, &p, (size_t)2 * f->parity_offset * lp->cplxBytes(), true);
   if (st) return st;
-  lp->scratch.push_back(p);
   f->data = p;
   return MUGIQ_HIP_SUCCESS;
 }
@@ -131,10 +156,8 @@ static int entry_basic(MugiqHipLoop *lp, int id, void *slot0) {
   void *send_d = nullptr, *recv_d = nullptr;
   if (part) {
     const size_t fb = (size_t)24 * (lp->volumeCB / lp->localL[dir]) * lp->cplxBytes();
-    if ((st = dev_alloc(lp, &send_d, fb, false))) return st;
-    lp->scratch.push_back(send_d);
-    if ((st = dev_alloc(lp, &recv_d, fb, false))) return st;
-    lp->scratch.push_back(recv_d);
+    if ((st = scratch_alloc(lp, &send_d, fb, false))) return st;
+    if ((st = scratch_alloc(lp, &recv_d, fb, false))) return st;
   }
   const size_t slotBytes = (size_t)lp->nElemPosLocPerLoop * lp->loopBytes();
   for (int n = 0; n < lp->nEv; n++) {  // lib/loop_mugiq.cpp:478
@@ -190,10 +213,8 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
   const int faceCB = lp->volumeCB / lp->localL[dir];
   if (part) {
     const size_t fb = (size_t)24 * faceCB * lp->cplxBytes();
-    if ((st = dev_alloc(lp, &send_d, fb, false))) return st;
-    lp->scratch.push_back(send_d);
-    if ((st = dev_alloc(lp, &recv_d, fb, false))) return st;
-    lp->scratch.push_back(recv_d);
+    if ((st = scratch_alloc(lp, &send_d, fb, false))) return st;
+    if ((st = scratch_alloc(lp, &recv_d, fb, false))) return st;
   }
   for (int k = 1; k <= stop; k++) {
     if (part && (st = exchange_face(lp, &E[k - 1], dir, sign, send_d, recv_d))) return st;
@@ -214,10 +235,8 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
     perVec = (size_t)stop * 24 * faceCB * lp->cplxBytes();
     const size_t budget = (size_t)4 << 30;  // 4 GiB per direction buffer
     nb = (int)std::max<size_t>(1, std::min<size_t>((size_t)lp->nEv, budget / perVec));
-    if ((st = dev_alloc(lp, &gsend, perVec * nb, false))) return st;
-    lp->scratch.push_back(gsend);
-    if ((st = dev_alloc(lp, &grecv, perVec * nb, false))) return st;
-    lp->scratch.push_back(grecv);
+    if ((st = scratch_alloc(lp, &gsend, perVec * nb, false))) return st;
+    if ((st = scratch_alloc(lp, &grecv, perVec * nb, false))) return st;
   }
   for (int n0 = 0; n0 < lp->nEv; n0 += nb) {
     const int nv = std::min(nb, lp->nEv - n0);
@@ -235,8 +254,16 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
   return MUGIQ_HIP_SUCCESS;
 }
 
+// hand the current entry's buffers back to the pool (the stream has been synchronised by the caller)
 static void free_scratch(MugiqHipLoop *lp) {
-  for (void *p : lp->scratch) (void)hipFree(p);
+  for (void *p : lp->scratch)
+    for (auto &b : lp->pool)
+      if (b.ptr == p) b.inUse = false;
+  lp->scratch.clear();
+}
+static void destroy_pool(MugiqHipLoop *lp) {
+  for (auto &b : lp->pool) (void)hipFree(b.ptr);
+  lp->pool.clear();
   lp->scratch.clear();
 }
 
@@ -686,7 +713,7 @@ int mugiq_hip_loop_write_hdf5(MugiqHipLoop *lp) {
 
 int mugiq_hip_loop_destroy(MugiqHipLoop *lp) {  // freeDataMemory, lib/loop_mugiq.cpp:182-229
   if (!lp) return MUGIQ_HIP_SUCCESS;
-  free_scratch(lp);
+  destroy_pool(lp);
   free(lp->dataMom_bcast);
   free(lp->dataMom_h);
   free(lp->dataMom);

@@ -60,9 +60,9 @@ if a.ab_tile:
     prm = hip.MugiqLoopParam(gauge=g, calcType=hip.LOOP_CALC_TYPE_OPT_KERNEL)
     prm.set_displace_entry_string(a.entries)
     loop = hip.Loop_Mugiq(prm, fields, sig)
-    ts = {"0": [], "1": []}
+    ts = {"0": [], "1": [], "2": []}
     for r in range(a.reps + 1):
-        for t in ("0", "1"):
+        for t in ("0", "1", "2"):
             os.environ["MUGIQ_HIP_FUSED_TILE"] = t
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -72,7 +72,9 @@ if a.ab_tile:
                 ts[t].append(time.perf_counter() - t0)
     print(json.dumps({"lattice": X, "nev": a.nev, "entries": a.entries,
                       "streaming_median_s": float(np.median(ts["0"])), "tiled_median_s": float(np.median(ts["1"])),
-                      "streaming_all": ts["0"], "tiled_all": ts["1"]}))
+                      "column_tile_only_median_s": float(np.median(ts["2"])),
+                      "streaming_min_s": min(ts["0"]), "tiled_min_s": min(ts["1"]), "column_tile_only_min_s": min(ts["2"]),
+                      "streaming_all": ts["0"], "tiled_all": ts["1"], "column_tile_only_all": ts["2"]}))
     sys.exit(0)
 for plan in a.plans.split(","):
     prm = hip.MugiqLoopParam(gauge=g, calcType=hip.LOOP_CALC_TYPE_OPT_KERNEL if plan == "opt" else hip.LOOP_CALC_TYPE_BASIC_KERNEL)
