@@ -44,7 +44,6 @@ template <typename T> __device__ inline MUGIQ_GLOBAL T *as_global(T *p) { return
 template <typename F> struct alignas(2 * sizeof(F)) Cplx {
   F re, im;
 };
-template <typename F> __host__ __device__ inline Cplx<F> cmake(F re, F im) { return Cplx<F>{re, im}; }
 // a += conj(x) * y
 template <typename F> __device__ inline void cmadd_conj(Cplx<F> &a, const Cplx<F> &x, const Cplx<F> &y) {
   a.re = fma(x.re, y.re, a.re);
@@ -136,10 +135,6 @@ template <typename F> __device__ inline void trace_and_store(Cplx<F> *loop, cons
 }
 
 // ---- QUDA even-odd index helpers (upstream QUDA index_helper.cuh) --------------
-struct Dims4 {
-  int x[4];
-};
-
 __host__ __device__ inline void get_coords(int c[4], int x_cb, const int X[4], int parity) {
   const int za = x_cb / (X[0] >> 1);
   const int zb = za / X[1];
