@@ -86,13 +86,25 @@ __global__ __launch_bounds__(BLOCK) void loop_contract_kernel(ContractArgs<A> a)
 #pragma unroll
     for (int j = 0; j < DEPTH - 1; j++)
       if (j < a.nVec) load_spinor<F, A, ORDER, NT>(v[j], a.L[j], a.parity_offset, a.stride, parity, x_cb);
-    for (int n = 0; n < a.nVec; n += DEPTH) {
+    // steady state without data-dependent branches (a conditional load makes hipcc's wait-count pass fall back to
+    // vmcnt(0), which defeats the prefetch), then a guarded tail
+    int n = 0;
+    for (; n + 2 * DEPTH - 1 <= a.nVec; n += DEPTH) {
+#pragma unroll
+      for (int j = 0; j < DEPTH; j++) {
+        const int m = n + j;
+        if constexpr (DEPTH > 1) load_spinor<F, A, ORDER, NT>(v[(j + DEPTH - 1) % DEPTH], a.L[m + DEPTH - 1], a.parity_offset, a.stride, parity, x_cb);
+        else load_spinor<F, A, ORDER, NT>(v[0], a.L[m], a.parity_offset, a.stride, parity, x_cb);
+        accumulate_herm(diag, up, v[j], a.inv_sigma[m]);
+      }
+    }
+    for (; n < a.nVec; n += DEPTH) {
 #pragma unroll
       for (int j = 0; j < DEPTH; j++) {
         const int m = n + j;
         if (m < a.nVec) {
           const int pre = m + DEPTH - 1;
-          if (pre < a.nVec) load_spinor<F, A, ORDER, NT>(v[(j + DEPTH - 1) % DEPTH], a.L[pre], a.parity_offset, a.stride, parity, x_cb);
+          if (pre < a.nVec && (DEPTH == 1 || pre >= DEPTH - 1)) load_spinor<F, A, ORDER, NT>(v[(j + DEPTH - 1) % DEPTH], a.L[pre], a.parity_offset, a.stride, parity, x_cb);
           accumulate_herm(diag, up, v[j], a.inv_sigma[m]);
         }
       }
@@ -141,8 +153,8 @@ struct ContractTune {
 };
 static ContractTune contract_tune(bool same) {
   // sweep on MI355X, 32^4 x 200 fp64 (profiles/r01_contract_sweep.txt): non-temporal loads +4 %; block size and prefetch
-  // depth within 1 % of each other (4-6 waves/SIMD already cover the latency), so the leanest variant is the default
-  ContractTune t{256, 1, 1, 1};
+  // depth within 1 % of each other (4-6 waves/SIMD already cover the latency); XCD-contiguous order +2 %
+  ContractTune t{256, 2, 1, 1};
   if (const char *e = getenv("MUGIQ_HIP_CONTRACT_TUNE")) {
     int b = 0, d = 0, n = 0, w = 0;
     if (sscanf(e, "%d,%d,%d,%d", &b, &d, &n, &w) >= 3 && (b == 64 || b == 128 || b == 256 || b == 512) && d >= 1 && d <= 3 && (n == 0 || n == 1)) {
