@@ -190,6 +190,19 @@ int mugiq_hip_displaced_loop_contraction_fused_mixed(void *loopData_d, int loopP
                                                      int dispDir, int dispSign, const int commDim[4],
                                                      const void *ghostLayers_d, int layers, void *stream);
 
+/* The same restricted to a region, so the halo transfer can overlap the part that does not need it:
+ *   MUGIQ_HIP_REGION_INTERIOR: sites whose shifted reads x +- k mu stay inside the local lattice (ghostLayers_d not read,
+ *                              may still be in flight);   MUGIQ_HIP_REGION_BOUNDARY: the remaining sites;
+ *   INTERIOR followed by BOUNDARY on the same loop slots == MUGIQ_HIP_REGION_ALL. */
+#define MUGIQ_HIP_REGION_ALL 0
+#define MUGIQ_HIP_REGION_INTERIOR 1
+#define MUGIQ_HIP_REGION_BOUNDARY 2
+int mugiq_hip_displaced_loop_contraction_fused_region(void *loopData_d, int loopPrecision,
+                                                      const MugiqHipSpinorField *eVecs_h, const double *sigma_h, int nVec,
+                                                      const void *const *pathLinkFields_h, const int *kValues_h, int nK,
+                                                      int dispDir, int dispSign, const int commDim[4],
+                                                      const void *ghostLayers_d, int layers, int region, void *stream);
+
 /* ---- a8  Fourier phase matrix -------------------------------------------------------------------------- */
 /* createPhaseMatrixGPU<Float>(phaseMatrix_d, momMatrix_h, locV3, Nmom, FTSign, localL, totalL)
  * lib/contract_wrappers.cu:50-77, kernel lib/mugiq_util_kernels.cu:3-35.  commCoord[4] replaces QUDA's

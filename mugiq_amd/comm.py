@@ -142,13 +142,25 @@ class GridComm:
             return wrapped
 
         def c_sendrecv(ctx, send_d, recv_d, nbytes, dim, direction, stream):
-            # the driver enqueued the pack kernel on `stream`; torch's collectives order against torch's
-            # current stream, which mugiq_amd uses for every launch
+            # `stream` is the stream the driver ordered the pack kernel on (its compute stream, or its halo stream
+            # when the transfer overlaps the interior sites).  torch's collectives order against torch's CURRENT
+            # stream, so make `stream` current for the duration of the exchange.
             s = device_bytes(send_d, nbytes, self.device)
             r = device_bytes(recv_d, nbytes, self.device)
-            if self.backend == "gloo":
-                torch.cuda.current_stream().synchronize()
-            self.sendrecv(s, r, dim, direction)
+            cur = torch.cuda.current_stream(self.device)
+            ptr = int(stream) if stream else 0
+            ctxmgr = torch.cuda.stream(torch.cuda.ExternalStream(ptr, device=self.device)) if ptr != cur.cuda_stream else None
+            if ctxmgr is not None:
+                ctxmgr.__enter__()
+            try:
+                if self.backend == "gloo":
+                    torch.cuda.current_stream(self.device).synchronize()      # staging through the host
+                self.sendrecv(s, r, dim, direction)
+                if self.backend == "gloo":
+                    torch.cuda.current_stream(self.device).synchronize()
+            finally:
+                if ctxmgr is not None:
+                    ctxmgr.__exit__(None, None, None)
 
         def c_reduce(ctx, send_h, recv_h, n, prec):
             s = torch.from_numpy(host_array(send_h, n, prec))

@@ -261,18 +261,21 @@ static int launch_fused(FusedArgs<F, A> a, int dir, int sign, hipStream_t stream
 bool tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int precision, int partitioned);
 template <typename F, typename A, int ORDER>
 int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d, const int *kvals,
-               int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, hipStream_t stream);
+               int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, int region, hipStream_t stream);
 
 template <typename F, typename A, int ORDER>
 static int fused_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d,
                        const int *kvals, int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers,
-                       hipStream_t stream) {
+                       int region, hipStream_t stream) {
   {
     int kmax = 0;
     for (int i = 0; i < nK; i++) kmax = kvals[i] > kmax ? kvals[i] : kmax;
     if (tile_applicable(ev[0], dir, kmax, ev[0].precision, partitioned))
-      return tile_entry<F, A, ORDER>(loop_d, ev, sigma, nVec, E_d, kvals, nK, dir, sign, partitioned, ghost_d, layers, stream);
+      return tile_entry<F, A, ORDER>(loop_d, ev, sigma, nVec, E_d, kvals, nK, dir, sign, partitioned, ghost_d, layers, region, stream);
   }
+  // the streaming kernel has no interior / boundary split: when the dimension is partitioned it counts as boundary
+  if (region == MUGIQ_HIP_REGION_INTERIOR && partitioned) return MUGIQ_HIP_SUCCESS;
+  if (region == MUGIQ_HIP_REGION_BOUNDARY && !partitioned) return MUGIQ_HIP_SUCCESS;
   const size_t ptr_bytes = sizeof(void *) * (size_t)nVec;
   std::vector<unsigned char> host(ptr_bytes + sizeof(A) * (size_t)nVec);
   const void **hl = reinterpret_cast<const void **>(host.data());
@@ -361,11 +364,14 @@ int mugiq_hip_pack_face_layers(void *faces_d, const MugiqHipSpinorField *eVecs_h
   return pack_layers<float, 4>(faces_d, eVecs_h, nVec, dim, high, layers, s);
 }
 
-int mugiq_hip_displaced_loop_contraction_fused_mixed(void *loopData_d, int loopPrecision, const MugiqHipSpinorField *eVecs_h,
-                                                     const double *sigma_h, int nVec, const void *const *pathLinkFields_h,
-                                                     const int *kValues_h, int nK, int dispDir, int dispSign,
-                                                     const int commDim[4], const void *ghostLayers_d, int layers, void *stream) {
+int mugiq_hip_displaced_loop_contraction_fused_region(void *loopData_d, int loopPrecision, const MugiqHipSpinorField *eVecs_h,
+                                                      const double *sigma_h, int nVec, const void *const *pathLinkFields_h,
+                                                      const int *kValues_h, int nK, int dispDir, int dispSign,
+                                                      const int commDim[4], const void *ghostLayers_d, int layers, int region,
+                                                      void *stream) {
   const char *who = "mugiq_hip_displaced_loop_contraction_fused";
+  MUGIQ_REQUIRE(region == MUGIQ_HIP_REGION_ALL || region == MUGIQ_HIP_REGION_INTERIOR || region == MUGIQ_HIP_REGION_BOUNDARY,
+                "%s: invalid region %d", who, region);
   MUGIQ_REQUIRE(loopData_d && eVecs_h && sigma_h && pathLinkFields_h && kValues_h, "%s: NULL argument", who);
   MUGIQ_REQUIRE(nVec >= 1 && nK >= 1, "%s: nVec = %d, nK = %d must be >= 1", who, nVec, nK);
   MUGIQ_REQUIRE(dispDir >= 0 && dispDir < 4 && (dispSign == 0 || dispSign == 1), "%s: Got invalid dispDir and/or dispSign.", who);
@@ -382,7 +388,7 @@ int mugiq_hip_displaced_loop_contraction_fused_mixed(void *loopData_d, int loopP
     MUGIQ_REQUIRE(pathLinkFields_h[i] != nullptr, "%s: pathLinkFields_h[%d] is NULL", who, i);
     if (kValues_h[i] > kmax) kmax = kValues_h[i];
   }
-  if (part) {
+  if (part && region != MUGIQ_HIP_REGION_INTERIOR) {
     MUGIQ_REQUIRE(ghostLayers_d != nullptr, "%s: dim %d is partitioned but ghostLayers_d is NULL (halo exchange missing)", who,
                   dispDir);
     MUGIQ_REQUIRE(layers >= kmax && layers <= eVecs_h[0].X[dispDir],
@@ -395,7 +401,7 @@ int mugiq_hip_displaced_loop_contraction_fused_mixed(void *loopData_d, int loopP
                 "%s: loop precision %d with field precision %d is not supported", who, loopPrecision, p);
 #define MUGIQ_FUSED_GO(F, A, O)                                                                                                 \
   return fused_entry<F, A, O>(loopData_d, eVecs_h, sigma_h, nVec, pathLinkFields_h, kValues_h, nK, dispDir, dispSign, part,   \
-                              ghostLayers_d, layers, s)
+                              ghostLayers_d, layers, region, s)
   if (p == 8 && o == 2) MUGIQ_FUSED_GO(double, double, 2);
   if (p == 8 && o == 4) MUGIQ_FUSED_GO(double, double, 4);
   if (loopPrecision == 8 && o == 2) MUGIQ_FUSED_GO(float, double, 2);
@@ -403,6 +409,15 @@ int mugiq_hip_displaced_loop_contraction_fused_mixed(void *loopData_d, int loopP
   if (o == 2) MUGIQ_FUSED_GO(float, float, 2);
   MUGIQ_FUSED_GO(float, float, 4);
 #undef MUGIQ_FUSED_GO
+}
+
+int mugiq_hip_displaced_loop_contraction_fused_mixed(void *loopData_d, int loopPrecision, const MugiqHipSpinorField *eVecs_h,
+                                                     const double *sigma_h, int nVec, const void *const *pathLinkFields_h,
+                                                     const int *kValues_h, int nK, int dispDir, int dispSign,
+                                                     const int commDim[4], const void *ghostLayers_d, int layers, void *stream) {
+  return mugiq_hip_displaced_loop_contraction_fused_region(loopData_d, loopPrecision, eVecs_h, sigma_h, nVec, pathLinkFields_h,
+                                                           kValues_h, nK, dispDir, dispSign, commDim, ghostLayers_d, layers,
+                                                           MUGIQ_HIP_REGION_ALL, stream);
 }
 
 int mugiq_hip_displaced_loop_contraction_fused(void *loopData_d, const MugiqHipSpinorField *eVecs_h, const double *sigma_h,

@@ -15,6 +15,7 @@
 // case keeps the first-generation kernel), X[DIR] % TJ == 0, at most 3 slots per launch.
 #include "internal.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -47,6 +48,8 @@ template <typename F, typename A> struct TileArgs {
   int H;          // volumeCB / (X[DIR] * strideMu)
   int numCols;    // V / X[DIR]
   int nJT;        // X[DIR] / TJ
+  int jtBegin;    // tiles along mu handled by this launch: [jtBegin, jtBegin + jtCount)
+  int jtCount;
   int tileBytes;  // LDS bytes of the staging tile (W follows it)
 };
 
@@ -88,8 +91,8 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
   int p0 = 0, base = 0, faceIdx = 0;         // column tile
   int ePR = 1, rowsPerGroup = 1;             // row tile
   if constexpr (DIR >= 1) {
-    jt = blockIdx.x % a.nJT;
-    cc = blockIdx.x / a.nJT;
+    jt = a.jtBegin + blockIdx.x % a.jtCount;
+    cc = blockIdx.x / a.jtCount;
     j0 = jt * kTileTJ;
     int cid = cc * kTileCols + col;
     active = cid < a.numCols;
@@ -293,7 +296,7 @@ template <typename F, typename A, int ORDER> static int launch_tile(TileArgs<F, 
   const size_t redBytes = sizeof(Cplx<A>) * 12 * 8 * 64;            // epilogue exchange of the two spin halves
   if (shmem < redBytes) shmem = redBytes;
   a.tileBytes = (int)tileBytes;
-  unsigned nblocks = ((a.numCols + kTileCols - 1) / kTileCols) * a.nJT;
+  unsigned nblocks = ((a.numCols + kTileCols - 1) / kTileCols) * a.jtCount;
   if (dir == 0) {  // row tile: 2 groups of kTileCols/(X0/2) whole x-rows per workgroup
     const int ePR = a.X[0] / 2, rpg = kTileCols / ePR;
     nblocks = (unsigned)(a.volumeCB / ePR / rpg / 2);
@@ -341,7 +344,7 @@ bool tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int preci
 
 template <typename F, typename A, int ORDER>
 int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d, const int *kvals,
-               int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, hipStream_t stream) {
+               int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, int region, hipStream_t stream) {
   const size_t ptr_bytes = sizeof(void *) * (size_t)nVec;
   std::vector<unsigned char> host(ptr_bytes + sizeof(A) * (size_t)nVec);
   const void **hl = reinterpret_cast<const void **>(host.data());
@@ -387,15 +390,32 @@ int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma,
       a.k[s] = kvals[i];
       if (s < a.nslot && kvals[i] > a.kmax) a.kmax = kvals[i];
     }
-    st = launch_tile<F, A, ORDER>(a, dir, sign, stream);
-    if (st) return st;
+    // region 0: everything | 1: tiles whose shifted reads stay inside the local lattice | 2: tiles that read ghost layers
+    a.jtBegin = 0;
+    a.jtCount = a.nJT;
+    if (region != MUGIQ_HIP_REGION_ALL && dir >= 1) {
+      const int nb = partitioned ? std::min(a.nJT, (a.kmax + kTileTJ - 1) / kTileTJ) : 0;  // boundary tiles
+      if (region == MUGIQ_HIP_REGION_INTERIOR) {
+        a.jtBegin = sign == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : nb;
+        a.jtCount = a.nJT - nb;
+      } else {
+        a.jtBegin = sign == MUGIQ_HIP_DISP_SIGN_PLUS ? a.nJT - nb : 0;
+        a.jtCount = nb;
+      }
+    } else if (region == MUGIQ_HIP_REGION_BOUNDARY) {
+      a.jtCount = 0;  // the row tile (x, never partitioned here) has no boundary part
+    }
+    if (a.jtCount > 0) {
+      st = launch_tile<F, A, ORDER>(a, dir, sign, stream);
+      if (st) return st;
+    }
   }
   return MUGIQ_HIP_SUCCESS;
 }
 
 #define MUGIQ_TILE_INST(F, A, O)                                                                                                 \
   template int tile_entry<F, A, O>(void *, const MugiqHipSpinorField *, const double *, int, const void *const *, const int *, int, \
-                                   int, int, int, const void *, int, hipStream_t);
+                                   int, int, int, const void *, int, int, hipStream_t);
 MUGIQ_TILE_INST(double, double, 2)
 MUGIQ_TILE_INST(double, double, 4)
 MUGIQ_TILE_INST(float, float, 2)

@@ -62,6 +62,9 @@ struct MugiqHipLoop_s {
   bool haveComm = false;
   int commDim[4] = {0, 0, 0, 0};
   hipStream_t stream = nullptr;
+  // halo transfers run on their own stream so they overlap the interior part of the fused contraction
+  hipStream_t commStream = nullptr;
+  hipEvent_t evPacked = nullptr, evHalo = nullptr;
   // ---- data buffers (include/loop_mugiq.h:49-57, lib/loop_mugiq.cpp:101-158)
   long long nElemMomTotPerLoop = 0, nElemMomLocPerLoop = 0, nElemPosLocPerLoop = 0;
   long long nElemMomTot = 0, nElemMomLoc = 0, nElemPosLoc = 0, nElemPhMat = 0;
@@ -238,17 +241,36 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
     if ((st = scratch_alloc(lp, &gsend, perVec * nb, false))) return st;
     if ((st = scratch_alloc(lp, &grecv, perVec * nb, false))) return st;
   }
+  if (part && !lp->commStream) {
+    MUGIQ_CHECK_HIP(hipStreamCreateWithFlags(&lp->commStream, hipStreamNonBlocking));
+    MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&lp->evPacked, hipEventDisableTiming));
+    MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&lp->evHalo, hipEventDisableTiming));
+  }
   for (int n0 = 0; n0 < lp->nEv; n0 += nb) {
     const int nv = std::min(nb, lp->nEv - n0);
-    if (part) {
-      const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
-      if ((st = mugiq_hip_pack_face_layers(gsend, &lp->eVecs[n0], nv, dir, high, stop, lp->stream))) return st;
-      st = lp->comm.sendrecv(lp->comm.ctx, gsend, grecv, perVec * nv, dir, high ? +1 : -1, lp->stream);
-      if (st) return set_error(MUGIQ_HIP_ERROR_HIP, "halo sendrecv callback failed with status %d", st);
+    if (!part) {
+      if ((st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, &lp->eVecs[n0], &lp->sigma[n0], nv,
+                                                                  links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
+                                                                  nullptr, 0, MUGIQ_HIP_REGION_ALL, lp->stream)))
+        return st;
+      continue;
     }
-    if ((st = mugiq_hip_displaced_loop_contraction_fused_mixed(slot0, lp->loopPrecision, &lp->eVecs[n0], &lp->sigma[n0], nv,
-                                                               links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
-                                                               grecv, stop, lp->stream)))
+    // pack the face layers -> [comm stream] exchange them  ||  [compute stream] interior sites -> boundary sites
+    const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
+    if ((st = mugiq_hip_pack_face_layers(gsend, &lp->eVecs[n0], nv, dir, high, stop, lp->stream))) return st;
+    MUGIQ_CHECK_HIP(hipEventRecord(lp->evPacked, lp->stream));
+    MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, lp->evPacked, 0));
+    st = lp->comm.sendrecv(lp->comm.ctx, gsend, grecv, perVec * nv, dir, high ? +1 : -1, lp->commStream);
+    if (st) return set_error(MUGIQ_HIP_ERROR_HIP, "halo sendrecv callback failed with status %d", st);
+    MUGIQ_CHECK_HIP(hipEventRecord(lp->evHalo, lp->commStream));
+    if ((st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, &lp->eVecs[n0], &lp->sigma[n0], nv,
+                                                                links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
+                                                                grecv, stop, MUGIQ_HIP_REGION_INTERIOR, lp->stream)))
+      return st;
+    MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->stream, lp->evHalo, 0));
+    if ((st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, &lp->eVecs[n0], &lp->sigma[n0], nv,
+                                                                links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
+                                                                grecv, stop, MUGIQ_HIP_REGION_BOUNDARY, lp->stream)))
       return st;
   }
   return MUGIQ_HIP_SUCCESS;
@@ -719,6 +741,9 @@ int mugiq_hip_loop_destroy(MugiqHipLoop *lp) {  // freeDataMemory, lib/loop_mugi
   free(lp->dataMom);
   free(lp->dataPos);
   if (lp->fineStore) (void)hipFree(lp->fineStore);
+  if (lp->evPacked) (void)hipEventDestroy(lp->evPacked);
+  if (lp->evHalo) (void)hipEventDestroy(lp->evHalo);
+  if (lp->commStream) (void)hipStreamDestroy(lp->commStream);
   if (lp->dataPos_d) (void)hipFree(lp->dataPos_d);
   if (lp->dataPosMP_d) (void)hipFree(lp->dataPosMP_d);
   if (lp->dataMom_d) (void)hipFree(lp->dataMom_d);
