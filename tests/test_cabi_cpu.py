@@ -87,3 +87,24 @@ def test_python_layout_plumbing_matches_oracle_layout(hip, order):
     for _ in range(200):
         p, x, s, c = rng.integers(0, 2), rng.integers(0, 500), rng.integers(0, 4), rng.integers(0, 3)
         assert spinor_native_index(order, p, x, s, c, 512, 12 * 512) == orc.spinor_native_index(order, p, x, s, c, 512, 12 * 512)
+
+
+def test_missing_library_fails_loudly(hip, monkeypatch, tmp_path):
+    """No CPU fallback: if libmugiq_hip.so is not there, loading raises instead of degrading."""
+    from mugiq_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libmugiq_hip.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_does_not_import_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "mugiq_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "build" in dirpath:
+            continue
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                src = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "import oracle" not in src and "from oracle" not in src and "mugiq_oracle" not in src, os.path.join(dirpath, fn)

@@ -386,3 +386,82 @@ def test_fused_prolong_contract_matches_oracle(hip, prec, lprec, X, bs, nvec, ne
     loop2 = torch.zeros_like(loop)
     hip.performLoopContractionBatched(loop2, ff, ff, sg)
     assert rel_err(loop.cpu().numpy(), loop2.cpu().numpy()) < (1e-12 if lprec == 8 and prec == 8 else 1e-5)
+
+
+# ---- size-independent properties at BASELINE.json's full sizes -------------------------------------------------------
+def test_full_size_cfg2_properties(hip):
+    """configs[1] at full size (32^4, fp64, N_ev = 200; 40 GB of eigenvectors): the oracle cannot run this in seconds, so
+    check identities: sum_x L_1(x) = sum_n 1/sigma_n (unit-norm vectors); L_1 real; additivity over eigenvector subsets;
+    the trace identity tr over a Hermitian Gamma is real for the ultra-local loop (all 16 G(n) are Hermitian or
+    anti-Hermitian: G^dag = +-G)."""
+    X = (32, 32, 32, 32)
+    nev = 200
+    V = int(np.prod(X))
+    per = 24 * (V // 2)
+    big = torch.empty(nev * per, dtype=torch.complex128, device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4321)
+    f = []
+    for n in range(nev):
+        w = torch.complex(torch.randn(per, dtype=torch.float64, device="cuda", generator=g),
+                          torch.randn(per, dtype=torch.float64, device="cuda", generator=g))
+        w /= torch.linalg.vector_norm(w)
+        big[n * per:(n + 1) * per] = w
+        f.append(hip.SpinorField(X, 8, 2, data=big[n * per:(n + 1) * per]))
+        del w
+    sg = sigmas(nev)
+    loop = torch.zeros(16 * V, dtype=torch.complex128, device="cuda")
+    hip.performLoopContractionBatched(loop, f, f, sg)
+    expect = np.sum(1.0 / sg)
+    assert abs(loop[:V].sum().item() - expect) < 1e-10 * expect
+    assert torch.max(torch.abs(loop[:V].imag)).item() == 0.0
+    # additivity: contraction over [0,73) plus [73,200) on top == contraction over all
+    part = torch.zeros_like(loop)
+    hip.performLoopContractionBatched(part, f[:73], f[:73], sg[:73])
+    hip.performLoopContractionBatched(part, f[73:], f[73:], sg[73:])
+    assert (torch.max(torch.abs(part - loop)) / torch.max(torch.abs(loop))).item() < 1e-13
+    # G^dag = eta G with eta = +-1  =>  v^dag G v is real (eta = +1) or imaginary (eta = -1)
+    scale = torch.max(torch.abs(loop)).item()
+    for iG in range(16):
+        G = orc.gamma_dense(iG)
+        eta = 1 if np.array_equal(G.conj().T, G) else -1
+        assert np.array_equal(G.conj().T, eta * G)
+        comp = loop[V * iG:V * (iG + 1)]
+        off = comp.imag if eta == 1 else comp.real
+        assert torch.max(torch.abs(off)).item() < 1e-13 * scale, iG
+
+
+def test_full_size_cfg3_local_shape_plus_minus_displacement_identity(hip):
+    """configs[2] per-GPU shape (48x48x24x24), reduced N_ev: for Gamma = 1 the loop displaced by -k mu is the complex
+    conjugate of the one displaced by +k mu shifted by k mu, so their lattice sums are complex conjugates -- a
+    size-independent link between the two signs, the path links and the tiled kernels (all four axes)."""
+    X = (48, 48, 24, 24)
+    nev = 6
+    V = int(np.prod(X))
+    vcb = V // 2
+    f = []
+    for n in range(nev):
+        w = torch.randn(24 * vcb, dtype=torch.complex128, device="cuda")
+        w /= torch.linalg.vector_norm(w)
+        f.append(hip.SpinorField(X, 8, 2, data=w))
+    gauge = hip.GaugeField(X, (0, 0, 0, 0), 8)
+    m = torch.randn(4 * 2 * vcb, 3, 3, dtype=torch.complex128, device="cuda")
+    r0 = m[:, 0] / torch.linalg.vector_norm(m[:, 0], dim=-1, keepdim=True)
+    r1 = m[:, 1] - (r0.conj() * m[:, 1]).sum(-1, keepdim=True) * r0
+    r1 = r1 / torch.linalg.vector_norm(r1, dim=-1, keepdim=True)
+    r2 = m[:, 2] - (r0.conj() * m[:, 2]).sum(-1, keepdim=True) * r0
+    r2 = r2 - (r1.conj() * r2).sum(-1, keepdim=True) * r1
+    r2 = r2 / torch.linalg.vector_norm(r2, dim=-1, keepdim=True)
+    q = torch.stack([r0, r1, r2], dim=1).reshape(4, 2, vcb, 9).permute(1, 0, 3, 2).contiguous()
+    gauge.data.copy_(q.reshape(-1))
+    sg = sigmas(nev)
+    prm = hip.MugiqLoopParam(gauge=gauge).set_displace_entry_string("+x:1,3;-x:1,3;+y:1,3;-y:1,3;+z:1,3;-z:1,3;+t:1,3;-t:1,3")
+    loop = hip.Loop_Mugiq(prm, f, sg)
+    loop.computeCoarseLoop()
+    pos = loop.dataPos_d.view(loop.nLoop, 16, V)
+    for axis in range(4):
+        for k in range(3):
+            plus = pos[1 + 6 * axis + k, 0].sum().item()
+            minus = pos[1 + 6 * axis + 3 + k, 0].sum().item()
+            assert abs(plus - np.conj(minus)) < 1e-11 * max(abs(plus), 1e-3), (axis, k, plus, minus)
+    loop.close()
