@@ -258,16 +258,16 @@ def test_driver_mg_coarse_path(hip, calc, entries):
     loop.close()
 
 
+@pytest.mark.parametrize("X", [(4, 8, 4, 8), (8, 4, 4, 8), (6, 4, 12, 4), (16, 4, 4, 4)])
 @pytest.mark.parametrize("tile", ["0", "1"])
-def test_fused_plans_agree_tiled_and_streaming(hip, tile, monkeypatch):
+def test_fused_plans_agree_tiled_and_streaming(hip, tile, X, monkeypatch):
     """The LDS-tiled column kernel (csrc/fused_tile.hip) and the first-generation streaming kernel are two
     implementations of the same entry point: both must match the oracle (y, z, t use the tile when enabled)."""
     monkeypatch.setenv("MUGIQ_HIP_FUSED_TILE", tile)
-    X = (4, 8, 4, 8)
     nev = 3
     ev, Uo, f, U = _setup(hip, X, nev, 8, 2, 4242)
     sg = sigmas(nev)
-    entry = "+y:1,3;-y:2,3;+z:1,2;-z:1;+t:1,3;-t:1,3;+x:1,2;+t:5,6"
+    entry = "+y:1,3;-y:2,3;+z:1,2;-z:1;+t:1,3;-t:1,3;+x:1,2;-x:1,3;+t:5,6"
     prm = hip.MugiqLoopParam(gauge=U).set_displace_entry_string(entry)
     loop = hip.Loop_Mugiq(prm, f, sg)
     loop.computeCoarseLoop()
