@@ -85,9 +85,11 @@ __global__ __launch_bounds__(kPrTile *kPrGroups) void prolong_kernel(ProlongArgs
       Cplx<A> p0[2], p1[2];  // in(X; chi, j) for the two eigenvectors
 #pragma unroll
       for (int chi = 0; chi < 2; chi++) {
-        const Cplx<F> u = c0[(int64_t)(chi * a.NV + j) * a.Cstride], w = c1[(int64_t)(chi * a.NV + j) * a.Cstride];
-        p0[chi] = Cplx<A>{(A)u.re, (A)u.im};
-        p1[chi] = Cplx<A>{(A)w.re, (A)w.im};
+        typedef F vec2 __attribute__((ext_vector_type(2)));
+        const vec2 u = *as_global(reinterpret_cast<const vec2 *>(c0 + (int64_t)(chi * a.NV + j) * a.Cstride));
+        const vec2 w = *as_global(reinterpret_cast<const vec2 *>(c1 + (int64_t)(chi * a.NV + j) * a.Cstride));
+        p0[chi] = Cplx<A>{(A)u.x, (A)u.y};
+        p1[chi] = Cplx<A>{(A)w.x, (A)w.y};
       }
 #pragma unroll
       for (int sc = 0; sc < 12; sc++) {
