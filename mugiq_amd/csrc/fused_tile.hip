@@ -270,19 +270,28 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
     if (n + 2 < a.nVec) MUGIQ_TILE_STEP(n + 2, stageC, 1)
   }
 #undef MUGIQ_TILE_STEP
-  // ---- combine the two spin halves of every line, then the 16 gamma traces (lanes 0-31)
-  __syncthreads();
-  Cplx<A> *red = reinterpret_cast<Cplx<A> *>(smem);  // [12 waves][8][64 lanes]
-#pragma unroll
-  for (int i = 0; i < 8; i++) red[(wave * 8 + i) * 64 + lane] = acc[i];
-  __syncthreads();
-  if (active && computes && half == 0) {
+  // ---- epilogue: the two lane halves of a wave hold complementary halves of the 4x4 colour-traced spin matrix of the
+  // same 32 sites.  Exchange them with wavefront shuffles (lane ^ 32), then each half takes 8 of the 16 gamma traces.
+  if (computes) {
     Cplx<A> full[16];
 #pragma unroll
     for (int be = 0; be < 4; be++)
 #pragma unroll
-      for (int al = 0; al < 4; al++) full[be * 4 + al] = red[(wave * 8 + be * 2 + (al & 1)) * 64 + col + 32 * (al >> 1)];
-    trace_and_store(a.loop + (int64_t)slot * a.slot_stride, full, 2 * a.volumeCB, xmine + pmine * a.volumeCB);
+      for (int a2 = 0; a2 < 2; a2++) {
+        const Cplx<A> mine = acc[be * 2 + a2];
+        Cplx<A> theirs;
+        theirs.re = __shfl_xor(mine.re, 32);
+        theirs.im = __shfl_xor(mine.im, 32);
+        // al = 2*half + a2 is mine, al = 2*(1-half) + a2 the partner's (selects keep the register indices static)
+        full[be * 4 + a2] = half == 0 ? mine : theirs;
+        full[be * 4 + 2 + a2] = half == 0 ? theirs : mine;
+      }
+    if (active) {
+      Cplx<A> *out = a.loop + (int64_t)slot * a.slot_stride;
+      const int siteIdx = xmine + pmine * a.volumeCB;
+      if (half == 0) trace_and_store_range<A, 0, 8>(out, full, 2 * a.volumeCB, siteIdx);
+      else trace_and_store_range<A, 8, 16>(out, full, 2 * a.volumeCB, siteIdx);
+    }
   }
 }
 
@@ -292,9 +301,7 @@ template <typename F, typename A, int ORDER> static int launch_tile(TileArgs<F, 
   const int NP = dir >= 1 ? kTileTJ + a.kmax : kTileTJ;
   const int PHsel = NP <= 8 ? 4 : kTileMaxPos / 2;
   const size_t tileBytes = 2 * sizeof(Cplx<F>) * (size_t)(2 * PHsel) * 12 * kTileCols;  // two buffers, padded positions
-  size_t shmem = tileBytes + sizeof(Cplx<A>) * 12 * 9 * kTileCols;           // tiles + W
-  const size_t redBytes = sizeof(Cplx<A>) * 12 * 8 * 64;            // epilogue exchange of the two spin halves
-  if (shmem < redBytes) shmem = redBytes;
+  const size_t shmem = tileBytes + sizeof(Cplx<A>) * 12 * 9 * kTileCols;     // tiles + W
   a.tileBytes = (int)tileBytes;
   unsigned nblocks = ((a.numCols + kTileCols - 1) / kTileCols) * a.jtCount;
   if (dir == 0) {  // row tile: 2 groups of kTileCols/(X0/2) whole x-rows per workgroup

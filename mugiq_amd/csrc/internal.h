@@ -134,6 +134,21 @@ template <typename F> __device__ inline void trace_and_store(Cplx<F> *loop, cons
   }
 }
 
+// the same for the gamma channels [G0, G1) only (the tile kernel splits the 16 channels over the two lane halves)
+template <typename F, int G0, int G1> __device__ inline void trace_and_store_range(Cplx<F> *loop, const Cplx<F> acc[16], int V, int site) {
+#pragma unroll
+  for (int iG = G0; iG < G1; iG++) {
+    Cplx<F> t{F(0), F(0)};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++) add_phase(t, kGammaPhase[iG][s2], acc[s2 * 4 + kGammaColumn[iG][s2]]);
+    Cplx<F> *out = loop + (int64_t)V * iG + site;
+    Cplx<F> o = *out;
+    o.re += t.re;
+    o.im += t.im;
+    *out = o;
+  }
+}
+
 // ---- QUDA even-odd index helpers (upstream QUDA index_helper.cuh) --------------
 __host__ __device__ inline void get_coords(int c[4], int x_cb, const int X[4], int parity) {
   const int za = x_cb / (X[0] >> 1);
