@@ -335,6 +335,7 @@ bool tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int preci
   int mode = 1;  // MUGIQ_HIP_FUSED_TILE: 0 = streaming kernel only, 2 = column tile only (no row tile), default both
   if (const char *e = getenv("MUGIQ_HIP_FUSED_TILE")) mode = atoi(e);
   if (mode == 0 || (mode == 2 && dir == 0)) return false;
+  if (2 * (int64_t)ev.parity_offset >= (1LL << 31)) return false;  // the kernel keeps 32-bit element offsets
   if (dir == 0) {  // row tile: whole x-rows in LDS, no ghost handling
     const int ePR = ev.X[0] / 2;
     if (partitioned || ePR > kTileCols || kmax >= ev.X[0]) return false;
@@ -343,6 +344,7 @@ bool tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int preci
     return true;
   }
   if (ev.X[dir] % kTileTJ != 0) return false;
+  if (kmax > ev.X[dir]) return false;  // the staged window wraps at most once around the lattice
   if (kTileTJ + kmax > kTileMaxPos) return false;
   const int PHsel = kTileTJ + kmax <= 8 ? 4 : kTileMaxPos / 2;
   const size_t lds = (size_t)2 * 2 * precision * (2 * PHsel) * 12 * kTileCols + (size_t)16 * 12 * 9 * kTileCols;

@@ -190,10 +190,9 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
   const bool part = lp->commDim[dir] != 0;
   const int stop = lp->dispStop[id], start = lp->dispStart[id];
   int st;
-  if (part && stop > lp->localL[dir])
-    return set_error(MUGIQ_HIP_ERROR_UNSUPPORTED,
-                     "displacement length %d exceeds the local extent %d of a partitioned dimension; use calcType BASIC", stop,
-                     lp->localL[dir]);
+  // a displacement longer than the local extent of a partitioned dimension reaches past the nearest neighbour: the
+  // multi-layer halo cannot serve it, the step-by-step sequence (one face per step) can
+  if (part && stop > lp->localL[dir]) return entry_basic(lp, id, slot0);
   // path-ordered link products W_k as E_k = D^k E_0, E_0(x)(s,c) = delta_sc, s < 3
   std::vector<MugiqHipSpinorField> E(stop + 1);
   for (int k = 0; k <= stop; k++)

@@ -118,7 +118,9 @@ def gpu_worker(rank, world, port, grid, prec, order, calc_type):
     torch.cuda.set_device(0)
     import mugiq_amd as hip
     G = (4, 4, 8, 8)
-    disp = (["+t", "-t", "+z", "-z", "+x", "-y"], [1, 2, 1, 1, 1, 2], [3, 2, 2, 1, 1, 2])
+    # the last entry is longer than the local t extent on a t-partitioned grid: the OPT plan hands it to the
+    # step-by-step sequence (one halo per step) instead of the multi-layer halo
+    disp = (["+t", "-t", "+z", "-z", "+x", "-y", "-t"], [1, 2, 1, 1, 1, 2, 5], [3, 2, 2, 1, 1, 2, 5])
     moms = momenta_p2_le(2)
     FTSign = 1
     nev = 3

@@ -275,3 +275,45 @@ def test_fused_plans_agree_tiled_and_streaming(hip, tile, X, monkeypatch):
     ref = orc.compute_loop_position_space(ev, sg, orc.LoopComputeParam(s, a, b), Uo, X)
     assert rel_err(loop.dataPos_d.cpu().numpy(), ref) < 1e-12
     loop.close()
+
+
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    X = tuple(int(v) for v in rng.choice([2, 4, 6, 8, 12], size=4))
+    while np.prod(X) > 4096 or np.prod(X) < 64:
+        X = tuple(int(v) for v in rng.choice([2, 4, 6, 8, 12], size=4))
+    prec, order = [(8, 2), (8, 4), (4, 2), (4, 4)][int(rng.integers(4))]
+    nev = int(rng.integers(1, 6))
+    ents = []
+    for _ in range(int(rng.integers(1, 6))):
+        d = "xyzt"[int(rng.integers(4))]
+        a, b = int(rng.integers(1, 8)), int(rng.integers(1, 8))        # lengths may exceed the extent (wraps) and start > stop
+        ents.append("%s%s:%d,%d" % ("+-"[int(rng.integers(2))], d, a, b) if rng.integers(3) else "%s%s:%d" % ("+-"[int(rng.integers(2))], d, a))
+    return X, prec, order, nev, ";".join(ents)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_driver_random_shapes_both_fused_plans(hip, seed, monkeypatch):
+    """Seeded random lattice shapes (extents from 2 to 12), storage types, eigenvector counts and displacement entries
+    (lengths past the extent, start > stop) through the OPT plan with the tiled and the streaming kernels."""
+    X, prec, order, nev, entry = _random_case(1000 + seed)
+    ev, Uo, f, U = _setup(hip, X, nev, prec, order, 77 + seed)
+    sg = sigmas(nev)
+    _, s, a, b = orc.parse_disp_entry_string(entry)
+    ref = orc.compute_loop_position_space(ev, np.float32(sg).astype(np.float64) if prec == 4 else sg, orc.LoopComputeParam(s, a, b), Uo, X)
+    cprm = orc.LoopComputeParam(s, a, b)
+    moms = momenta_p2_le(2)
+    FTSign = 1 if seed % 2 else -1
+    V, locV3 = int(np.prod(X)), X[0] * X[1] * X[2]
+    ref_mom = orc.momentum_projection_local(orc.convert_idx_order_map_gamma(ref, cprm.nData, cprm.nLoop, 2, V // 2, X),
+                                            orc.phase_matrix(moms, locV3, FTSign, X, X), X[3], cprm.nData, locV3, len(moms))
+    tol = 1e-12 if prec == 8 else 2e-5
+    for tile in ("1", "0"):
+        monkeypatch.setenv("MUGIQ_HIP_FUSED_TILE", tile)
+        prm = hip.MugiqLoopParam(gauge=U, FTSign=FTSign, doMomProj=True, momMatrix=[list(m) for m in moms], Nmom=len(moms))
+        loop = hip.Loop_Mugiq(prm.set_displace_entry_string(entry), f, sg)
+        loop.computeCoarseLoop()
+        err = rel_err(loop.dataPos_d.cpu().numpy(), ref)
+        err_mom = rel_err(loop.dataMom_bcast, ref_mom)
+        loop.close()
+        assert err < tol and err_mom < tol, (X, prec, order, nev, entry, tile, err, err_mom)
