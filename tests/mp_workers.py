@@ -110,17 +110,16 @@ def cpu_worker(rank, world, port, grid):
     dist.destroy_process_group()
 
 
-def gpu_worker(rank, world, port, grid, prec, order, calc_type):
+def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8)):
     """The C++ driver on every rank (all on cuda:0), halos and FT reduction through the comm callbacks."""
     import torch
     from util import orc, momenta_p2_le, rel_err
     dist = _init(rank, world, port)
     torch.cuda.set_device(0)
     import mugiq_amd as hip
-    G = (4, 4, 8, 8)
     # the last entry is longer than the local t extent on a t-partitioned grid: the OPT plan hands it to the
     # step-by-step sequence (one halo per step) instead of the multi-layer halo
-    disp = (["+t", "-t", "+z", "-z", "+x", "-y", "-t"], [1, 2, 1, 1, 1, 2, 5], [3, 2, 2, 1, 1, 2, 5])
+    disp = (["+t", "-t", "+z", "-z", "+x", "-y", "-t", "+y"], [1, 2, 1, 1, 1, 2, 5, 1], [3, 2, 2, 1, 1, 2, 5, 3])
     moms = momenta_p2_le(2)
     FTSign = 1
     nev = 3

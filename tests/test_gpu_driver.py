@@ -13,14 +13,14 @@ from util import orc, random_gauge_lex, random_spinor_lex, sigmas, momenta_p2_le
 pytestmark = pytest.mark.gpu
 
 
-def _setup(hip, X, nev, prec, order, seed):
+def _setup(hip, X, nev, prec, order, seed, pad=0, gpad=0):
     rng = np.random.default_rng(seed)
     cdt = np.complex128 if prec == 8 else np.complex64
     ev = [orc.lex_to_eo(random_spinor_lex(rng, X), X).astype(cdt).astype(np.complex128) for _ in range(nev)]
     Uo = orc.extended_gauge_from_global(random_gauge_lex(rng, X), (0, 0, 0, 0), (1, 1, 1, 1), (0, 0, 0, 0))
     Uo = Uo.astype(cdt).astype(np.complex128)
-    f = [hip.SpinorField(X, prec, order).set_logical(v) for v in ev]
-    U = hip.GaugeField(X, (0, 0, 0, 0), prec).set_logical(Uo)
+    f = [hip.SpinorField(X, prec, order, pad=pad).set_logical(v) for v in ev]
+    U = hip.GaugeField(X, (0, 0, 0, 0), prec, pad=gpad).set_logical(Uo)
     return ev, Uo, f, U
 
 
@@ -132,9 +132,17 @@ def test_fused_operator_with_ghost_layers(hip, order):
 
 
 @pytest.mark.parametrize("grid,prec,order,calc", [((1, 1, 1, 2), 8, 2, 1), ((1, 1, 2, 1), 8, 4, 1), ((1, 1, 1, 2), 8, 2, 2),
-                                                  ((1, 1, 2, 1), 4, 4, 2), ((2, 1, 1, 1), 4, 2, 1)])
+                                                  ((1, 1, 2, 1), 4, 4, 2), ((2, 1, 1, 1), 4, 2, 1), ((1, 2, 1, 1), 8, 2, 2)])
 def test_two_rank_driver_on_one_gpu(grid, prec, order, calc):
     mp.spawn(mp_workers.gpu_worker, args=(2, free_port(), grid, prec, order, calc), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("grid,G,prec,order", [((1, 1, 1, 2), (4, 4, 8, 16), 8, 2), ((1, 1, 2, 1), (4, 8, 16, 4), 8, 4),
+                                               ((1, 2, 1, 1), (4, 16, 4, 4), 4, 4)])
+def test_two_rank_driver_interior_boundary_tiles(grid, G, prec, order):
+    """Local extent 8 along the partitioned axis: the tiled kernel runs its INTERIOR tiles while the halo is in flight and
+    its BOUNDARY tiles afterwards (two tiles along the axis)."""
+    mp.spawn(mp_workers.gpu_worker, args=(2, free_port(), grid, prec, order, 2, G), nprocs=2, join=True)
 
 
 def test_driver_writes_reference_hdf5_tree(hip, tmp_path):
@@ -289,15 +297,16 @@ def _random_case(seed):
         d = "xyzt"[int(rng.integers(4))]
         a, b = int(rng.integers(1, 8)), int(rng.integers(1, 8))        # lengths may exceed the extent (wraps) and start > stop
         ents.append("%s%s:%d,%d" % ("+-"[int(rng.integers(2))], d, a, b) if rng.integers(3) else "%s%s:%d" % ("+-"[int(rng.integers(2))], d, a))
-    return X, prec, order, nev, ";".join(ents)
+    pad, gpad = int(rng.choice([0, 0, 6, 32])), int(rng.choice([0, 0, 10]))      # stride = volumeCB + pad (QUDA's pad)
+    return X, prec, order, nev, ";".join(ents), pad, gpad
 
 
 @pytest.mark.parametrize("seed", range(48))
 def test_driver_random_shapes_both_fused_plans(hip, seed, monkeypatch):
     """Seeded random lattice shapes (extents from 2 to 12), storage types, eigenvector counts and displacement entries
     (lengths past the extent, start > stop) through the OPT plan with the tiled and the streaming kernels."""
-    X, prec, order, nev, entry = _random_case(1000 + seed)
-    ev, Uo, f, U = _setup(hip, X, nev, prec, order, 77 + seed)
+    X, prec, order, nev, entry, pad, gpad = _random_case(1000 + seed)
+    ev, Uo, f, U = _setup(hip, X, nev, prec, order, 77 + seed, pad, gpad)
     sg = sigmas(nev)
     _, s, a, b = orc.parse_disp_entry_string(entry)
     ref = orc.compute_loop_position_space(ev, np.float32(sg).astype(np.float64) if prec == 4 else sg, orc.LoopComputeParam(s, a, b), Uo, X)
@@ -316,4 +325,4 @@ def test_driver_random_shapes_both_fused_plans(hip, seed, monkeypatch):
         err = rel_err(loop.dataPos_d.cpu().numpy(), ref)
         err_mom = rel_err(loop.dataMom_bcast, ref_mom)
         loop.close()
-        assert err < tol and err_mom < tol, (X, prec, order, nev, entry, tile, err, err_mom)
+        assert err < tol and err_mom < tol, (X, prec, order, nev, entry, pad, gpad, tile, err, err_mom)
