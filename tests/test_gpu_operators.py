@@ -388,6 +388,57 @@ def test_fused_prolong_contract_matches_oracle(hip, prec, lprec, X, bs, nvec, ne
     assert rel_err(loop.cpu().numpy(), loop2.cpu().numpy()) < (1e-12 if lprec == 8 and prec == 8 else 1e-5)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_geometry_contraction_and_prolongator(hip, seed):
+    """Seeded random shapes through the operator entry points: batch sizes around the kernels' prefetch depth, padded
+    strides, L == R and L != R, mixed precision; transfer operators with random aggregate shapes and n_vec."""
+    rng = np.random.default_rng(5000 + seed)
+    ext = [2, 4, 6, 8, 12]
+    X = tuple(int(v) for v in rng.choice(ext, size=4))
+    while np.prod(X) > 4096:
+        X = tuple(int(v) for v in rng.choice(ext, size=4))
+    V = int(np.prod(X))
+    prec, order = CASES[int(rng.integers(4))]
+    lprec = 8 if (prec == 4 and rng.integers(2)) else prec
+    nev = int(rng.integers(1, 10))
+    pad = int(rng.choice([0, 0, 2, 18, 64]))
+    same = bool(rng.integers(2))
+    evL = [orc.lex_to_eo(random_spinor_lex(rng, X), X) for _ in range(nev)]
+    evR = evL if same else [orc.lex_to_eo(random_spinor_lex(rng, X), X) for _ in range(nev)]
+    sg = sigmas(nev)
+    fL = [_field(hip, v, X, prec, order, pad) for v in evL]
+    fR = fL if same else [_field(hip, v, X, prec, order, pad) for v in evR]
+    ref = np.zeros(16 * V, dtype=np.complex128)
+    for n in range(nev):
+        orc.loop_contract(ref, _rounded(evL[n], prec), _rounded(evR[n], prec), float(np.float32(sg[n])) if prec == 4 else sg[n])
+    loop = torch.zeros(16 * V, dtype=torch.complex128 if lprec == 8 else torch.complex64, device="cuda")
+    hip.performLoopContractionBatched(loop, fL, fR, sg)
+    tol = 1e-12 if lprec == 8 else 1e-5
+    assert rel_err(loop.cpu().numpy(), ref) < tol, (X, prec, order, lprec, nev, pad, same)
+
+    # prolongator: aggregates that divide X into even coarse extents
+    bs = tuple(int(rng.choice([b for b in (1, 2, 3, 4, 6) if X[d] % b == 0 and (X[d] // b) % 2 == 0])) for d in range(4))
+    nvec = int(rng.choice([1, 2, 3, 5, 8, 24, 32]))
+    ncv = int(rng.integers(1, 40))
+    Vn, phis, Xc = _mg_problem(X, bs, nvec, ncv, 6000 + seed)
+    cdt = _np_c(prec)
+    Vn = Vn.astype(cdt)
+    phis = [q.astype(cdt) for q in phis]
+    T = hip.Transfer(X, nvec, bs, 2, prec).set_logical(Vn)
+    cf = [hip.CoarseField(Xc, nvec, prec).set_logical(q) for q in phis]
+    ff = [hip.SpinorField(X, prec, order, pad=pad) for _ in range(ncv)]
+    hip.prolongateEvecs(ff, cf, T)
+    sg2 = sigmas(ncv)
+    ref2 = np.zeros(16 * V, dtype=np.complex128)
+    for n in range(ncv):
+        psi = orc.prolongate(phis[n].astype(np.complex128), Vn.astype(np.complex128), X, bs)
+        assert rel_err(ff[n].get_logical(), psi) < (1e-13 if prec == 8 else 2e-6), (X, bs, nvec, ncv, n)
+        orc.loop_contract(ref2, psi, psi, float(np.float32(sg2[n])) if prec == 4 else sg2[n])
+    loop2 = torch.zeros(16 * V, dtype=torch.complex128 if lprec == 8 else torch.complex64, device="cuda")
+    hip.prolongateContractBatched(loop2, cf, sg2, T)
+    assert rel_err(loop2.cpu().numpy(), ref2) < tol, (X, bs, nvec, ncv, prec, lprec)
+
+
 # ---- size-independent properties at BASELINE.json's full sizes -------------------------------------------------------
 def test_full_size_cfg2_properties(hip):
     """configs[1] at full size (32^4, fp64, N_ev = 200; 40 GB of eigenvectors): the oracle cannot run this in seconds, so
