@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmugiq_hip.so")
+# MUGIQ_HIP_LIB selects another build of the same library (e.g. a diagnostic build); never a different backend
+LIB_PATH = os.environ.get("MUGIQ_HIP_LIB") or os.path.join(_HERE, "libmugiq_hip.so")
 
 
 class MugiqHipError(RuntimeError):

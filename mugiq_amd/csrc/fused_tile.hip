@@ -51,6 +51,7 @@ template <typename F, typename A> struct TileArgs {
   int jtBegin;    // tiles along mu handled by this launch: [jtBegin, jtBegin + jtCount)
   int jtCount;
   int tileBytes;  // LDS bytes of the staging tile (W follows it)
+  int blockOrder; // workgroup -> tile map (see the kernel)
 };
 
 // complex-element offset of component `comp` at checkerboard index idx inside one parity block of a field / ghost zone
@@ -72,7 +73,11 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
   const int lane = threadIdx.x & 63;
   const int col = lane & 31, half = lane >> 5;
   const int wave = threadIdx.x >> 6;
+#if defined(MUGIQ_TILE_EXPERIMENT) && MUGIQ_TILE_EXPERIMENT == 1
+  const bool computes = false;  // diagnostic build: staging traffic only
+#else
   const bool computes = wave < kTileTJ * a.nslot;
+#endif
   const int NP = (DIR >= 1) ? kTileTJ + a.kmax : kTileTJ;
   const int J = a.X[DIR];
 
@@ -86,13 +91,24 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
   const int wpos = wave % kTileTJ;  // this wave's own position index (jj for the column tile)
   const int slot = wave / kTileTJ;
   const int k = a.k[slot];
-  int jt = 0, cc = blockIdx.x, j0 = 0;
+  int blk = blockIdx.x;
+  if (a.blockOrder & 2) {  // XCD-contiguous: workgroups are dealt round-robin over the 8 XCDs
+    const int per = gridDim.x >> 3;
+    blk = (blk & 7) * per + (blk >> 3);
+  }
+  int jt = 0, cc = blk, j0 = 0;
   bool active;
   int p0 = 0, base = 0, faceIdx = 0;         // column tile
   int ePR = 1, rowsPerGroup = 1;             // row tile
   if constexpr (DIR >= 1) {
-    jt = a.jtBegin + blockIdx.x % a.jtCount;
-    cc = blockIdx.x / a.jtCount;
+    if (a.blockOrder & 1) {  // consecutive workgroups = consecutive column groups (adjacent 512-byte runs)
+      const int nCC = gridDim.x / a.jtCount;
+      jt = a.jtBegin + blk / nCC;
+      cc = blk % nCC;
+    } else {
+      jt = a.jtBegin + blk % a.jtCount;
+      cc = blk / a.jtCount;
+    }
     j0 = jt * kTileTJ;
     int cid = cc * kTileCols + col;
     active = cid < a.numCols;
@@ -180,8 +196,17 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
   for (int i = 0; i < 8; i++) acc[i] = Cplx<A>{A(0), A(0)};
 
   typedef F vec2 __attribute__((ext_vector_type(2)));
-  vec2 stageA[PH], stageB[PH], stageC[PH];  // three eigenvectors in flight ahead of the one being consumed (latency!)
+  // Three eigenvectors in flight ahead of the one being consumed.  Diagnostic builds on MI355X (-DMUGIQ_TILE_EXPERIMENT,
+  // 48.48.24.24 fp64, 100 eigenvectors, 10.0 ms per entry): staging only 5.9 ms, compute only 7.0 ms (6.9 ms without the
+  // barrier); SQ counters: the VALU pipe of a SIMD is ~64 % busy, 82 % of its instructions are the FMAs of the
+  // mathematics -- the kernel is bound by vector issue, not by HBM or LDS.  Tried without gain: 6-deep prefetch for
+  // fp32 storage (25 % slower), a pair-wise LDS layout so that fp32 reads are ds_read_b128 instead of ds_read2_b64 (no
+  // change), column groups as the fastest workgroup index (4 % slower).
+  vec2 stageA[PH], stageB[PH], stageC[PH];
   // fetch this lane's share of eigenvector n_: plane `wave`, column `col`, positions pp = 2*i + half
+#if defined(MUGIQ_TILE_EXPERIMENT) && MUGIQ_TILE_EXPERIMENT >= 2
+#define MUGIQ_TILE_FETCH(n_, stage) { _Pragma("unroll") for (int i = 0; i < PH; i++) stage[i] = vec2{F(n_), F(1)}; } /* diagnostic: no global loads */
+#else
 #define MUGIQ_TILE_FETCH(n_, stage)                                                                                    \
   {                                                                                                                    \
     const Cplx<F> *body_ = static_cast<const Cplx<F> *>(a.L[n_]);                                                      \
@@ -191,16 +216,21 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
       stage[i] = *as_global(reinterpret_cast<const vec2 *>(ptr_));                                                     \
     }                                                                                                                  \
   }
+#endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() lowers to `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`,
 // i.e. it also drains every global load in flight -- which would serialise the register prefetch of the next
 // eigenvectors behind each barrier.  The stage registers are guarded by the compiler's own counted vmcnt waits.
+#if defined(MUGIQ_TILE_EXPERIMENT) && MUGIQ_TILE_EXPERIMENT == 3
+#define MUGIQ_LDS_BARRIER() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } /* diagnostic: no barrier (racy) */
+#else
 #define MUGIQ_LDS_BARRIER()                              \
   {                                                      \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
     __builtin_amdgcn_s_barrier();                        \
     asm volatile("" ::: "memory");                       \
   }
+#endif
 
 // One step: eigenvector n_ is in LDS buffer n_ % 2; `stage` holds eigenvector n_+1 (fetched three steps ago).
 // Commit n_+1 into the other buffer (everyone finished reading it before the barrier that ended the previous step),
@@ -308,6 +338,11 @@ template <typename F, typename A, int ORDER> static int launch_tile(TileArgs<F, 
     const int ePR = a.X[0] / 2, rpg = kTileCols / ePR;
     nblocks = (unsigned)(a.volumeCB / ePR / rpg / 2);
   }
+  // workgroup order, measured on MI355X (48.48.24.24, 100 eigenvectors): XCD-contiguous with the tiles along mu as the
+  // fastest index is 2.5 % (fp64) / 1.5 % (fp32) faster than the plain order
+  a.blockOrder = 2;
+  if (const char *e = getenv("MUGIQ_HIP_TILE_ORDER")) a.blockOrder = atoi(e) & 3;
+  if (nblocks % 8 != 0) a.blockOrder &= 1;
   const dim3 grid(nblocks), block(64 * 12);
 #define MUGIQ_TILE_LAUNCH(D, S, P)                                                                                    \
   {                                                                                                                   \

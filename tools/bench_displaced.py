@@ -22,6 +22,7 @@ ap.add_argument("--entries", default="+x:1,3;-x:1,3;+y:1,3;-y:1,3;+z:1,3;-z:1,3;
 ap.add_argument("--plans", default="opt,basic")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--ab-tile", action="store_true", help="alternate MUGIQ_HIP_FUSED_TILE=0/1 in one process (interleaved rounds)")
+ap.add_argument("--ab-env", default=None, help="NAME=v1,v2,...: alternate an environment knob of the library in one process")
 a = ap.parse_args()
 
 X = tuple(a.lattice)
@@ -56,6 +57,25 @@ g.data.copy_(q.reshape(-1).to(cdt))
 sig = 0.01 + 0.002 * np.arange(a.nev)
 B = a.precision
 res = {}
+if a.ab_env:
+    name, vals = a.ab_env.split("=")
+    vals = vals.split(",")
+    prm = hip.MugiqLoopParam(gauge=g, calcType=hip.LOOP_CALC_TYPE_OPT_KERNEL)
+    prm.set_displace_entry_string(a.entries)
+    loop = hip.Loop_Mugiq(prm, fields, sig)
+    ts = {v: [] for v in vals}
+    for r in range(a.reps + 1):
+        for v in vals:
+            os.environ[name] = v
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loop.computeCoarseLoop()
+            torch.cuda.synchronize()
+            if r > 0:
+                ts[v].append(time.perf_counter() - t0)
+    print(json.dumps({"lattice": X, "nev": a.nev, "precision": a.precision, "order": a.order, "entries": a.entries, "knob": name,
+                      "median_s": {v: float(np.median(ts[v])) for v in vals}, "min_s": {v: min(ts[v]) for v in vals}}))
+    sys.exit(0)
 if a.ab_tile:
     prm = hip.MugiqLoopParam(gauge=g, calcType=hip.LOOP_CALC_TYPE_OPT_KERNEL)
     prm.set_displace_entry_string(a.entries)
