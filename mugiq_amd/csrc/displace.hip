@@ -162,6 +162,28 @@ static int launch_pack(void *face_d, const MugiqHipSpinorField *src, int dim, in
   return MUGIQ_HIP_SUCCESS;
 }
 
+// E_0 of the fused plan: the FLOAT2 field whose first three spin rows are the 3x3 identity, E_0(x)(s,c) = delta_sc for
+// s < 3, and zero elsewhere (its k-fold displacement is the path-ordered link product W_k)
+template <typename F> __global__ __launch_bounds__(256) void identity_links_kernel(Cplx<F> *data, int volumeCB, int64_t parity_offset) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * volumeCB) return;
+  const int pty = i >= volumeCB ? 1 : 0;
+  Cplx<F> *p = data + (int64_t)pty * parity_offset + (i - pty * volumeCB);
+#pragma unroll
+  for (int k = 0; k < 12; k++) p[(int64_t)k * volumeCB] = Cplx<F>{(k == 0 || k == 4 || k == 8) ? F(1) : F(0), F(0)};
+}
+
+int fill_identity_links(const MugiqHipSpinorField *f, hipStream_t stream) {
+  MUGIQ_REQUIRE(f && f->data && f->field_order == 2 && f->stride == f->volumeCB, "fill_identity_links: need a pad-0 FLOAT2 field");
+  const dim3 grid((2 * f->volumeCB + 255) / 256);
+  if (f->precision == 8)
+    hipLaunchKernelGGL(identity_links_kernel<double>, grid, dim3(256), 0, stream, static_cast<Cplx<double> *>(f->data), f->volumeCB, f->parity_offset);
+  else
+    hipLaunchKernelGGL(identity_links_kernel<float>, grid, dim3(256), 0, stream, static_cast<Cplx<float> *>(f->data), f->volumeCB, f->parity_offset);
+  MUGIQ_CHECK_HIP(hipGetLastError());
+  return MUGIQ_HIP_SUCCESS;
+}
+
 int validate_gauge(const MugiqHipGaugeField *U, const MugiqHipSpinorField *ref, const char *who) {
   MUGIQ_REQUIRE(U != nullptr && U->data != nullptr, "%s: gauge field is NULL", who);
   MUGIQ_REQUIRE(U->precision == ref->precision,

@@ -30,6 +30,7 @@ int device_scratch(void **ptr, size_t bytes);
 // caller's memory may be released on return).  Tables of successive calls reuse the same scratch: calls
 // must be issued on one stream at a time per device (the reference's wrappers are not re-entrant either).
 int upload_table(void **dev, const void *host, size_t bytes, hipStream_t stream);
+int fill_identity_links(const MugiqHipSpinorField *f, hipStream_t stream);  // displace.hip
 
 // ---- address spaces ---------------------------------------------------------------------------------------------
 // Pointers fetched from a device-side table (eigenvector bodies) have no known address space, so hipcc emits

@@ -122,14 +122,14 @@ static int scratch_alloc(MugiqHipLoop *lp, void **p, size_t bytes, bool zero) {
 }
 
 // A FLOAT2, pad-0 scratch field with the eigenvectors' geometry (+ room for both depth-1 ghost zones of `dim`).
-static int make_scratch_field(MugiqHipLoop *lp, MugiqHipSpinorField *f, int order) {
+static int make_scratch_field(MugiqHipLoop *lp, MugiqHipSpinorField *f, int order, bool zero = false) {
   *f = lp->eVecs[0];
   f->field_order = order;
   f->stride = lp->volumeCB;
   f->parity_offset = (int64_t)12 * lp->volumeCB;
   for (int d = 0; d < 4; d++) f->ghost[d][0] = f->ghost[d][1] = nullptr;
   void *p = nullptr;
-  int st = scratch_alloc(lp, &p, (size_t)2 * f->parity_offset * lp->cplxBytes(), true);
+  int st = scratch_alloc(lp, &p, (size_t)2 * f->parity_offset * lp->cplxBytes(), zero);
   if (st) return st;
   f->data = p;
   return MUGIQ_HIP_SUCCESS;
@@ -155,7 +155,7 @@ static int entry_basic(MugiqHipLoop *lp, int id, void *slot0) {
   MugiqHipSpinorField aux[2];
   int st;
   for (int i = 0; i < 2; i++)
-    if ((st = make_scratch_field(lp, &aux[i], lp->order))) return st;
+    if ((st = make_scratch_field(lp, &aux[i], lp->order))) return st;  // fully written by every displacement
   void *send_d = nullptr, *recv_d = nullptr;
   if (part) {
     const size_t fb = (size_t)24 * (lp->volumeCB / lp->localL[dir]) * lp->cplxBytes();
@@ -196,21 +196,8 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
   // path-ordered link products W_k as E_k = D^k E_0, E_0(x)(s,c) = delta_sc, s < 3
   std::vector<MugiqHipSpinorField> E(stop + 1);
   for (int k = 0; k <= stop; k++)
-    if ((st = make_scratch_field(lp, &E[k], 2))) return st;
-  {
-    const size_t one = lp->cplxBytes();
-    std::vector<unsigned char> plane((size_t)lp->volumeCB * one, 0);
-    for (int i = 0; i < lp->volumeCB; i++) {
-      if (lp->precision == 8) reinterpret_cast<double *>(plane.data())[2 * i] = 1.0;
-      else reinterpret_cast<float *>(plane.data())[2 * i] = 1.0f;
-    }
-    for (int pty = 0; pty < 2; pty++)
-      for (int s = 0; s < 3; s++) {
-        char *dstp = static_cast<char *>(E[0].data) + ((size_t)pty * E[0].parity_offset + (size_t)(s * 3 + s) * lp->volumeCB) * one;
-        MUGIQ_CHECK_HIP(hipMemcpyAsync(dstp, plane.data(), plane.size(), hipMemcpyHostToDevice, lp->stream));
-      }
-    MUGIQ_CHECK_HIP(hipStreamSynchronize(lp->stream));  // `plane` leaves scope
-  }
+    if ((st = make_scratch_field(lp, &E[k], 2, false))) return st;  // every site of E_k is written below
+  if ((st = fill_identity_links(&E[0], lp->stream))) return st;
   void *send_d = nullptr, *recv_d = nullptr;
   const int faceCB = lp->volumeCB / lp->localL[dir];
   if (part) {
