@@ -9,7 +9,10 @@ template <typename T, int CHAINS> __global__ __launch_bounds__(256) void fma_ker
   for (int i = 0; i < CHAINS; i++) x[i] = T(threadIdx.x + i);
   for (int it = 0; it < iters; it++) {
 #pragma unroll
-    for (int i = 0; i < CHAINS; i++) x[i] = __builtin_fma(x[i], a, b);
+    for (int i = 0; i < CHAINS; i++) {
+      if constexpr (sizeof(T) == 8) x[i] = __builtin_fma(x[i], a, b);
+      else x[i] = __builtin_fmaf(x[i], a, b);
+    }
   }
   T s = 0;
 #pragma unroll
