@@ -202,14 +202,26 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
   // mathematics -- the kernel is bound by vector issue, not by HBM or LDS.  Tried without gain: 6-deep prefetch for
   // fp32 storage (25 % slower), a pair-wise LDS layout so that fp32 reads are ds_read_b128 instead of ds_read2_b64 (no
   // change), column groups as the fastest workgroup index (4 % slower).
+  const Cplx<F> *body0 = static_cast<const Cplx<F> *>(a.L[0]);
+  (void)body0;
   vec2 stageA[PH], stageB[PH], stageC[PH];
   // fetch this lane's share of eigenvector n_: plane `wave`, column `col`, positions pp = 2*i + half
-#if defined(MUGIQ_TILE_EXPERIMENT) && MUGIQ_TILE_EXPERIMENT >= 2
-#define MUGIQ_TILE_FETCH(n_, stage) { _Pragma("unroll") for (int i = 0; i < PH; i++) stage[i] = vec2{F(n_), F(1)}; } /* diagnostic: no global loads */
+#if defined(MUGIQ_TILE_EXPERIMENT) && MUGIQ_TILE_EXPERIMENT == 4 /* diagnostic: no table look-ups (contiguous fields) */
+#define MUGIQ_TILE_BODY(n_) (body0 + (int64_t)(n_) * 2 * a.parity_offset)
+#define MUGIQ_TILE_SIGMA(n_) A(1)
 #else
-#define MUGIQ_TILE_FETCH(n_, stage)                                                                                    \
+#define MUGIQ_TILE_BODY(n_) static_cast<const Cplx<F> *>(a.L[n_])
+#define MUGIQ_TILE_SIGMA(n_) a.inv_sigma[n_]
+#define MUGIQ_TILE_SCALAR_PREFETCH 1
+#endif
+#if defined(MUGIQ_TILE_EXPERIMENT) && (MUGIQ_TILE_EXPERIMENT == 2 || MUGIQ_TILE_EXPERIMENT == 3)
+#define MUGIQ_TILE_FETCH(n_, stage) { _Pragma("unroll") for (int i = 0; i < PH; i++) stage[i] = vec2{F(n_), F(1)}; } /* diagnostic: no global loads */
+#define MUGIQ_TILE_FETCH_AT(bodyExpr_, n_, stage) MUGIQ_TILE_FETCH(n_, stage)
+#else
+#define MUGIQ_TILE_FETCH(n_, stage) MUGIQ_TILE_FETCH_AT(MUGIQ_TILE_BODY(n_), n_, stage)
+#define MUGIQ_TILE_FETCH_AT(bodyExpr_, n_, stage)                                                                      \
   {                                                                                                                    \
-    const Cplx<F> *body_ = static_cast<const Cplx<F> *>(a.L[n_]);                                                      \
+    const Cplx<F> *body_ = bodyExpr_;                                                                                  \
     const Cplx<F> *gh_ = ghostBase + (int64_t)(n_)*a.ghost_vec_stride;                                                 \
     _Pragma("unroll") for (int i = 0; i < PH; i++) { /* unconditional: every lane and slot has a valid source */       \
       const Cplx<F> *ptr_ = (((sghost >> i) & 1u) ? gh_ : body_) + soff[i];                                            \
@@ -244,9 +256,15 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
       _Pragma("unroll") for (int i = 0; i < PH; i++)                                                                   \
         nxt[((2 * i + half) * 12 + wave) * kTileCols + col] = Cplx<F>{stage[i].x, stage[i].y};                         \
     }                                                                                                                  \
-    if (GUARD == 0 || (n_) + 4 < a.nVec) MUGIQ_TILE_FETCH((n_) + 4, stage)                                             \
+    if (GUARD == 0 || (n_) + 4 < a.nVec) MUGIQ_TILE_FETCH_AT(bodyPre, (n_) + 4, stage)                                 \
+    const A s = sigPre;                                                                                                \
+    { /* table look-ups of the NEXT step, issued now so that their latency hides behind this step's LDS reads (after   \
+         the barrier every wave would sit on them at once); clamped, hence unconditional */                           \
+      const int nb_ = (n_) + 5 < a.nVec ? (n_) + 5 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1;      \
+      bodyPre = MUGIQ_TILE_BODY(nb_);                                                                                  \
+      sigPre = MUGIQ_TILE_SIGMA(ns_);                                                                                  \
+    }                                                                                                                  \
     if (computes) {                                                                                                    \
-      const A s = a.inv_sigma[n_];                                                                                     \
       const Cplx<F> *tl = tile + (ppL * 12) * kTileCols + col;                                                         \
       const Cplx<F> *ts = tile + (ppS * 12 + half * 6) * kTileCols + colS; /* spins 2*half, 2*half + 1 */              \
       /* t[a2] = s * W * psi[2*half + a2]: each W element and each psi element is read from LDS once */               \
@@ -285,6 +303,8 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
   if (a.nVec > 1) MUGIQ_TILE_FETCH(1, stageA)
   if (a.nVec > 2) MUGIQ_TILE_FETCH(2, stageB)
   if (a.nVec > 3) MUGIQ_TILE_FETCH(3, stageC)
+  const Cplx<F> *bodyPre = MUGIQ_TILE_BODY(a.nVec > 4 ? 4 : a.nVec - 1);
+  A sigPre = MUGIQ_TILE_SIGMA(0);
   MUGIQ_LDS_BARRIER()
   // steady state without any data-dependent branch (hipcc's wait-count pass turns every conditional load into a
   // conservative `vmcnt(0)`, which would serialise the prefetch), then a guarded tail
@@ -326,6 +346,9 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
 }
 
 #undef MUGIQ_TILE_FETCH
+#undef MUGIQ_TILE_FETCH_AT
+#undef MUGIQ_TILE_BODY
+#undef MUGIQ_TILE_SIGMA
 
 template <typename F, typename A, int ORDER> static int launch_tile(TileArgs<F, A> a, int dir, int sign, hipStream_t stream) {
   const int NP = dir >= 1 ? kTileTJ + a.kmax : kTileTJ;
