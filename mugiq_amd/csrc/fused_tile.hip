@@ -210,8 +210,8 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
 #define MUGIQ_TILE_BODY(n_) (body0 + (int64_t)(n_) * 2 * a.parity_offset)
 #define MUGIQ_TILE_SIGMA(n_) A(1)
 #else
-#define MUGIQ_TILE_BODY(n_) static_cast<const Cplx<F> *>(a.L[n_])
-#define MUGIQ_TILE_SIGMA(n_) a.inv_sigma[n_]
+#define MUGIQ_TILE_BODY(n_) static_cast<const Cplx<F> *>(as_constant(a.L)[n_])
+#define MUGIQ_TILE_SIGMA(n_) as_constant(a.inv_sigma)[n_]
 #define MUGIQ_TILE_SCALAR_PREFETCH 1
 #endif
 #if defined(MUGIQ_TILE_EXPERIMENT) && (MUGIQ_TILE_EXPERIMENT == 2 || MUGIQ_TILE_EXPERIMENT == 3)
@@ -251,19 +251,21 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
 #define MUGIQ_TILE_STEP(n_, stage, GUARD)                                                                              \
   {                                                                                                                    \
     const Cplx<F> *tile = tileBase + (size_t)((n_) & 1) * tileElems;                                                   \
+    const A s = sigPre;                                                                                                \
+    const Cplx<F> *bodyNow = bodyPre;                                                                                  \
+    { /* table look-ups of the NEXT step, issued first: they complete while this step waits for its staged loads, and  \
+         being scalar loads in flight they would otherwise turn the first LDS wait of the arithmetic into lgkmcnt(0) */ \
+      const int nb_ = (n_) + 5 < a.nVec ? (n_) + 5 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1;      \
+      bodyPre = MUGIQ_TILE_BODY(nb_);                                                                                  \
+      sigPre = MUGIQ_TILE_SIGMA(ns_);                                                                                  \
+    }                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0); /* keep them first */                                                           \
     if (GUARD == 0 || (n_) + 1 < a.nVec) {                                                                             \
       Cplx<F> *nxt = tileBase + (size_t)(((n_) + 1) & 1) * tileElems;                                                  \
       _Pragma("unroll") for (int i = 0; i < PH; i++)                                                                   \
         nxt[((2 * i + half) * 12 + wave) * kTileCols + col] = Cplx<F>{stage[i].x, stage[i].y};                         \
     }                                                                                                                  \
-    if (GUARD == 0 || (n_) + 4 < a.nVec) MUGIQ_TILE_FETCH_AT(bodyPre, (n_) + 4, stage)                                 \
-    const A s = sigPre;                                                                                                \
-    { /* table look-ups of the NEXT step, issued now so that their latency hides behind this step's LDS reads (after   \
-         the barrier every wave would sit on them at once); clamped, hence unconditional */                           \
-      const int nb_ = (n_) + 5 < a.nVec ? (n_) + 5 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1;      \
-      bodyPre = MUGIQ_TILE_BODY(nb_);                                                                                  \
-      sigPre = MUGIQ_TILE_SIGMA(ns_);                                                                                  \
-    }                                                                                                                  \
+    if (GUARD == 0 || (n_) + 4 < a.nVec) MUGIQ_TILE_FETCH_AT(bodyNow, (n_) + 4, stage)                                 \
     if (computes) {                                                                                                    \
       const Cplx<F> *tl = tile + (ppL * 12) * kTileCols + col;                                                         \
       const Cplx<F> *ts = tile + (ppS * 12 + half * 6) * kTileCols + colS; /* spins 2*half, 2*half + 1 */              \
@@ -300,9 +302,15 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
   MUGIQ_TILE_FETCH(0, stageC)
 #pragma unroll
   for (int i = 0; i < PH; i++) tileBase[((2 * i + half) * 12 + wave) * kTileCols + col] = Cplx<F>{stageC[i].x, stageC[i].y};
-  if (a.nVec > 1) MUGIQ_TILE_FETCH(1, stageA)
-  if (a.nVec > 2) MUGIQ_TILE_FETCH(2, stageB)
-  if (a.nVec > 3) MUGIQ_TILE_FETCH(3, stageC)
+  // unconditional (clamped) so that the steady-state loop is entered with a KNOWN number of loads in flight: with
+  // conditional prologue loads hipcc's wait-count pass waited for vmcnt(0) at the first commit of every loop iteration,
+  // i.e. for the loads issued one step earlier -- the three-deep prefetch was in effect one deep
+  {
+    const int last = a.nVec - 1;
+    MUGIQ_TILE_FETCH((1 < last ? 1 : last), stageA)
+    MUGIQ_TILE_FETCH((2 < last ? 2 : last), stageB)
+    MUGIQ_TILE_FETCH((3 < last ? 3 : last), stageC)
+  }
   const Cplx<F> *bodyPre = MUGIQ_TILE_BODY(a.nVec > 4 ? 4 : a.nVec - 1);
   A sigPre = MUGIQ_TILE_SIGMA(0);
   MUGIQ_LDS_BARRIER()

@@ -40,6 +40,11 @@ int fill_identity_links(const MugiqHipSpinorField *f, hipStream_t stream);  // d
 #define MUGIQ_GLOBAL __attribute__((address_space(1)))
 template <typename T> __device__ inline const MUGIQ_GLOBAL T *as_global(const T *p) { return (const MUGIQ_GLOBAL T *)p; }
 template <typename T> __device__ inline MUGIQ_GLOBAL T *as_global(T *p) { return (MUGIQ_GLOBAL T *)p; }
+// Tables the host uploads before the launch and the kernel never writes (pointer / 1/sigma tables): the constant
+// address space lets hipcc fetch a wave-uniform entry with s_load (lgkmcnt) instead of a vector load, which would
+// share the in-order vmcnt queue with the prefetched eigenvector loads and drain it at every use.
+#define MUGIQ_CONSTANT __attribute__((address_space(4)))
+template <typename T> __device__ inline const MUGIQ_CONSTANT T *as_constant(const T *p) { return (const MUGIQ_CONSTANT T *)p; }
 
 // ---- complex arithmetic in registers -------------------------------------------------------------
 template <typename F> struct alignas(2 * sizeof(F)) Cplx {
