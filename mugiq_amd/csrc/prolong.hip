@@ -81,25 +81,56 @@ __global__ __launch_bounds__(kPrTile *kPrGroups) void prolong_kernel(ProlongArgs
     Cplx<A> o0[12], o1[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) o0[k] = o1[k] = Cplx<A>{A(0), A(0)};
-    for (int j = 0; j < a.NV; j++) {
-      Cplx<A> p0[2], p1[2];  // in(X; chi, j) for the two eigenvectors
-#pragma unroll
-      for (int chi = 0; chi < 2; chi++) {
-        typedef F vec2 __attribute__((ext_vector_type(2)));
-        const vec2 u = *as_global(reinterpret_cast<const vec2 *>(c0 + (int64_t)(chi * a.NV + j) * a.Cstride));
-        const vec2 w = *as_global(reinterpret_cast<const vec2 *>(c1 + (int64_t)(chi * a.NV + j) * a.Cstride));
-        p0[chi] = Cplx<A>{(A)u.x, (A)u.y};
-        p1[chi] = Cplx<A>{(A)w.x, (A)w.y};
+    // The null-vector index j runs through a three-stage register pipeline: the 12 LDS reads of V(x; :, j) and the four
+    // L2 reads of the coarse components are issued two steps before the 96 FMAs that consume them (the plain loop
+    // waited for both latencies in every iteration: the VALU was ~45 % busy; 32^4, n_vec 24, 200 eigenvectors:
+    // prolongate-to-fine 36 -> 29 ms).  All loads are unconditional (index clamped) so that hipcc's wait-count pass
+    // keeps counted waits.
+    typedef F vec2 __attribute__((ext_vector_type(2)));
+    Cplx<F> sv0[12], sv1[12], sv2[12];
+    vec2 sp0[4], sp1[4], sp2[4];  // [chi] of eigenvector n0, [2 + chi] of eigenvector n1
+#define MUGIQ_PR_LOAD(sv, sp, jexpr)                                                                                   \
+  {                                                                                                                    \
+    const int j_ = (jexpr) < a.NV ? (jexpr) : a.NV - 1;                                                                \
+    _Pragma("unroll") for (int chi = 0; chi < 2; chi++) {                                                              \
+      sp[chi] = *as_global(reinterpret_cast<const vec2 *>(c0 + (int64_t)(chi * a.NV + j_) * a.Cstride));               \
+      sp[2 + chi] = *as_global(reinterpret_cast<const vec2 *>(c1 + (int64_t)(chi * a.NV + j_) * a.Cstride));           \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int sc = 0; sc < 12; sc++) sv[sc] = Vt[(sc * a.NV + j_) * kPrTile + site];                  \
+  }
+#define MUGIQ_PR_COMPUTE(sv, sp)                                                                                       \
+  {                                                                                                                    \
+    const Cplx<A> p0[2] = {Cplx<A>{(A)sp[0].x, (A)sp[0].y}, Cplx<A>{(A)sp[1].x, (A)sp[1].y}};                          \
+    const Cplx<A> p1[2] = {Cplx<A>{(A)sp[2].x, (A)sp[2].y}, Cplx<A>{(A)sp[3].x, (A)sp[3].y}};                          \
+    _Pragma("unroll") for (int sc = 0; sc < 12; sc++) {                                                                \
+      const Cplx<A> v{(A)sv[sc].re, (A)sv[sc].im};                                                                     \
+      const int chi = (sc / 3) / 2; /* spin_map(s) = s / spin_bs with spin_bs = 2 (tests/loop.cpp:569) */              \
+      cmadd(o0[sc], v, p0[chi]);                                                                                       \
+      cmadd(o1[sc], v, p1[chi]);                                                                                       \
+    }                                                                                                                  \
+  }
+    if constexpr (CONTRACT) {
+      // with the 16 Hermitian accumulators on top, three stages do not fit 256 VGPRs any more (fp64: one wave per SIMD
+      // plus accumulation-register traffic): measured 21.6 ms against 17.5 ms for the plain loop in fp64, 12.3 ms
+      // against 10.9 ms in fp32 -- the fused variant keeps the plain loop
+      for (int j = 0; j < a.NV; j++) {
+        MUGIQ_PR_LOAD(sv0, sp0, j)
+        MUGIQ_PR_COMPUTE(sv0, sp0)
       }
-#pragma unroll
-      for (int sc = 0; sc < 12; sc++) {
-        const Cplx<F> vv = Vt[(sc * a.NV + j) * kPrTile + site];
-        const Cplx<A> v{(A)vv.re, (A)vv.im};
-        const int chi = (sc / 3) / 2;  // spin_map(s) = s / spin_bs with spin_bs = 2 (tests/loop.cpp:569)
-        cmadd(o0[sc], v, p0[chi]);
-        cmadd(o1[sc], v, p1[chi]);
+    } else {
+      MUGIQ_PR_LOAD(sv0, sp0, 0)
+      MUGIQ_PR_LOAD(sv1, sp1, 1)
+      for (int j = 0; j < a.NV; j += 3) {
+        MUGIQ_PR_LOAD(sv2, sp2, j + 2)
+        MUGIQ_PR_COMPUTE(sv0, sp0)
+        MUGIQ_PR_LOAD(sv0, sp0, j + 3)
+        if (j + 1 < a.NV) MUGIQ_PR_COMPUTE(sv1, sp1)
+        MUGIQ_PR_LOAD(sv1, sp1, j + 4)
+        if (j + 2 < a.NV) MUGIQ_PR_COMPUTE(sv2, sp2)
       }
     }
+#undef MUGIQ_PR_LOAD
+#undef MUGIQ_PR_COMPUTE
     if constexpr (WRITE) {
       if (valid) {
         Cplx<F> w[12];
