@@ -22,21 +22,31 @@ struct MomProjGeom {
   long long K;
   long long kChunk;  // k-range per split
   int nSplit;
+  int RT;            // rows per lane (1, 2 or 4)
 };
 
-template <typename F>
+// RT rows per lane (m, m + 256, ...): every phase read from LDS feeds RT complex multiply-adds.  With one row per lane
+// the broadcast LDS reads (one ds_read_b128 per 4 FMAs, shared by the four SIMDs of a CU) cost as much as the
+// arithmetic; wider momentum tiles do not change that ratio (measured: NT = 32 was 40 % slower than NT = 8).
+template <typename F, int RT>
 __global__ __launch_bounds__(kMpBlock) void momproj_partial_kernel(Cplx<F> *part, const Cplx<F> *A, const Cplx<F> *B,
                                                                    MomProjGeom g) {
   __shared__ Cplx<F> Bs[kMpKC][kMpNT];
-  const int m = blockIdx.x * kMpBlock + threadIdx.x;
+  const int m0 = blockIdx.x * (kMpBlock * RT) + threadIdx.x;
   const int n0 = blockIdx.y * kMpNT;
   const int split = blockIdx.z;
   const long long kBeg = split * g.kChunk;
   const long long kEnd = (kBeg + g.kChunk < g.K) ? kBeg + g.kChunk : g.K;
 
-  Cplx<F> acc[kMpNT];
+  Cplx<F> acc[RT][kMpNT];
 #pragma unroll
-  for (int n = 0; n < kMpNT; n++) acc[n] = Cplx<F>{F(0), F(0)};
+  for (int r = 0; r < RT; r++)
+#pragma unroll
+    for (int n = 0; n < kMpNT; n++) acc[r][n] = Cplx<F>{F(0), F(0)};
+  // rows beyond M re-read the last row (valid address, result dropped): no divergence around the loads
+  int mr[RT];
+#pragma unroll
+  for (int r = 0; r < RT; r++) mr[r] = (m0 + r * kMpBlock < g.M) ? m0 + r * kMpBlock : g.M - 1;
 
   for (long long k0 = kBeg; k0 < kEnd; k0 += kMpKC) {
     __syncthreads();
@@ -47,21 +57,29 @@ __global__ __launch_bounds__(kMpBlock) void momproj_partial_kernel(Cplx<F> *part
       Bs[kk][n] = b;
     }
     __syncthreads();
-    if (m < g.M) {
-      const int kn = (int)((kEnd - k0 < kMpKC) ? (kEnd - k0) : kMpKC);
-      const Cplx<F> *a = A + m + (long long)g.M * k0;
-#pragma unroll 4
-      for (int kk = 0; kk < kn; kk++) {
-        const Cplx<F> av = a[(long long)g.M * kk];
+    const int kn = (int)((kEnd - k0 < kMpKC) ? (kEnd - k0) : kMpKC);
+    const Cplx<F> *a = A + (long long)g.M * k0;
+#pragma unroll 2
+    for (int kk = 0; kk < kn; kk++) {
+      Cplx<F> av[RT];
 #pragma unroll
-        for (int n = 0; n < kMpNT; n++) cmadd(acc[n], av, Bs[kk][n]);
+      for (int r = 0; r < RT; r++) av[r] = a[(long long)g.M * kk + mr[r]];
+#pragma unroll
+      for (int n = 0; n < kMpNT; n++) {
+        const Cplx<F> b = Bs[kk][n];
+#pragma unroll
+        for (int r = 0; r < RT; r++) cmadd(acc[r][n], av[r], b);
       }
     }
   }
-  if (m < g.M) {
 #pragma unroll
-    for (int n = 0; n < kMpNT; n++)
-      if (n0 + n < g.N) part[((long long)split * g.N + (n0 + n)) * g.M + m] = acc[n];
+  for (int r = 0; r < RT; r++) {
+    const int m = m0 + r * kMpBlock;
+    if (m < g.M) {
+#pragma unroll
+      for (int n = 0; n < kMpNT; n++)
+        if (n0 + n < g.N) part[((long long)split * g.N + (n0 + n)) * g.M + m] = acc[r][n];
+    }
   }
 }
 
@@ -82,7 +100,9 @@ static void choose_split(int M, int N, long long K, MomProjGeom &g) {
   g.M = M;
   g.N = N;
   g.K = K;
-  const long long tiles = (long long)((M + kMpBlock - 1) / kMpBlock) * ((N + kMpNT - 1) / kMpNT);
+  g.RT = M >= 4 * kMpBlock ? 4 : (M >= 2 * kMpBlock ? 2 : 1);
+  const int rowsPerWg = kMpBlock * g.RT;
+  const long long tiles = (long long)((M + rowsPerWg - 1) / rowsPerWg) * ((N + kMpNT - 1) / kMpNT);
   long long want = (2048 + tiles - 1) / tiles;  // ~8 workgroups per CU
   const long long maxSplit = (K + 4 * kMpKC - 1) / (4 * kMpKC);  // keep >= 256 k-values per split
   if (want > maxSplit) want = maxSplit;
@@ -95,10 +115,13 @@ static void choose_split(int M, int N, long long K, MomProjGeom &g) {
 
 template <typename F>
 static int launch_momproj(void *C, const void *A, const void *B, const MomProjGeom &g, void *ws, hipStream_t stream) {
-  const dim3 grid((g.M + kMpBlock - 1) / kMpBlock, (g.N + kMpNT - 1) / kMpNT, g.nSplit);
+  const int rowsPerWg = kMpBlock * g.RT;
+  const dim3 grid((g.M + rowsPerWg - 1) / rowsPerWg, (g.N + kMpNT - 1) / kMpNT, g.nSplit);
   Cplx<F> *part = g.nSplit == 1 ? static_cast<Cplx<F> *>(C) : static_cast<Cplx<F> *>(ws);
-  hipLaunchKernelGGL((momproj_partial_kernel<F>), grid, dim3(kMpBlock), 0, stream, part, static_cast<const Cplx<F> *>(A),
-                     static_cast<const Cplx<F> *>(B), g);
+  const Cplx<F> *Ap = static_cast<const Cplx<F> *>(A), *Bp = static_cast<const Cplx<F> *>(B);
+  if (g.RT == 4) hipLaunchKernelGGL((momproj_partial_kernel<F, 4>), grid, dim3(kMpBlock), 0, stream, part, Ap, Bp, g);
+  else if (g.RT == 2) hipLaunchKernelGGL((momproj_partial_kernel<F, 2>), grid, dim3(kMpBlock), 0, stream, part, Ap, Bp, g);
+  else hipLaunchKernelGGL((momproj_partial_kernel<F, 1>), grid, dim3(kMpBlock), 0, stream, part, Ap, Bp, g);
   MUGIQ_CHECK_HIP(hipGetLastError());
   if (g.nSplit > 1) {
     const long long MN = (long long)g.M * g.N;
