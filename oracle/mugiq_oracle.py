@@ -13,7 +13,9 @@ are restated from upstream QUDA (include/index_helper.cuh, color_spinor_field_or
 gauge_field_order.h; circa v1.0 / early-2020 develop) and marked ASSUMED below.  The oracle is
 anchored instead by analytic known-answer tests (tests/test_oracle_kat.py): gamma-algebra
 identities, D_-mu D_+mu = 1, gauge covariance, periodic wrap, direct DFT, multi-domain ==
-single-domain.
+single-domain.  The literal tables of the reference's headers (gamma row values / column
+indices / names, gamma5 map, displacement flags) ARE pinned against the header text where the
+reference is mounted (tests/test_reference_tables.py).
 
 Every function cites the reference file:line it follows (paths relative to /root/reference).
 
