@@ -95,3 +95,41 @@ def test_hdf5_group_formats_equal_the_reference_source():
     sizes = dict(re.findall(r"char (group[12]_tag)\[(\d+)\]", ref))
     assert sizes == {"group1_tag": "16", "group2_tag": "10"}
     assert dict(re.findall(r"char (group[12]_tag)\[(\d+)\]", ours)) == sizes
+
+
+def _c_enum(src, name):
+    """name -> {enumerator: value} of a C enum in `src` (implicit values count up from the previous one)"""
+    body = re.search(r"typedef enum %s\s*\{(.*?)\}" % name, re.sub(r"//[^\n]*", "", src), re.S).group(1)
+    out, nxt = {}, 0
+    for item in [x.strip() for x in body.split(",") if x.strip()]:
+        if "=" in item:
+            k, v = [t.strip() for t in item.split("=")]
+            if not re.fullmatch(r"-?\d+", v):
+                continue                                                   # "= MUGIQ_INVALID_ENUM"
+            nxt = int(v)
+        else:
+            k = item
+        out[k] = nxt
+        nxt += 1
+    return out
+
+
+def test_enumerator_values_equal_the_reference_header(hip):
+    src = open("/root/reference/include/enum_mugiq.h").read()              # include/enum_mugiq.h:29-85
+    inc = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mugiq_hip.h")).read()
+    mine = {k: int(v) for k, v in re.findall(r"#define (MUGIQ_HIP_[A-Z_]+) (-?\d+)\b", inc)}
+    calc = _c_enum(src, "LoopCalcType_s")
+    assert {k: mine["MUGIQ_HIP_" + k] for k in ("LOOP_CALC_TYPE_BLAS", "LOOP_CALC_TYPE_OPT_KERNEL", "LOOP_CALC_TYPE_BASIC_KERNEL")} == \
+        {k: calc[k] for k in ("LOOP_CALC_TYPE_BLAS", "LOOP_CALC_TYPE_OPT_KERNEL", "LOOP_CALC_TYPE_BASIC_KERNEL")}
+    assert (hip.LOOP_CALC_TYPE_BLAS, hip.LOOP_CALC_TYPE_OPT_KERNEL, hip.LOOP_CALC_TYPE_BASIC_KERNEL) == \
+        (calc["LOOP_CALC_TYPE_BLAS"], calc["LOOP_CALC_TYPE_OPT_KERNEL"], calc["LOOP_CALC_TYPE_BASIC_KERNEL"])
+    d = _c_enum(src, "DisplaceDir_s")
+    assert [mine["MUGIQ_HIP_DISP_DIR_" + c] for c in "XYZT"] == [d["DispDir_" + c] for c in "xyzt"]
+    sg = _c_enum(src, "DisplaceSign_s")
+    assert (mine["MUGIQ_HIP_DISP_SIGN_MINUS"], mine["MUGIQ_HIP_DISP_SIGN_PLUS"]) == (sg["DispSignMinus"], sg["DispSignPlus"])
+    assert (hip.DispSignMinus, hip.DispSignPlus) == (sg["DispSignMinus"], sg["DispSignPlus"])
+    assert (orc.DISP_SIGN_MINUS, orc.DISP_SIGN_PLUS) == (sg["DispSignMinus"], sg["DispSignPlus"])
+    fl = _c_enum(src, "DisplaceFlag_s")
+    assert [fl["DispFlag_" + c] for c in "XxYyZzTt"] == list(range(8))     # the order DISPLACE_FLAGS relies on
+    ft = _c_enum(src, "LoopFTSign_s")
+    assert (ft["LOOP_FT_SIGN_MINUS"], ft["LOOP_FT_SIGN_PLUS"]) == (-1, 1)
