@@ -50,7 +50,7 @@ template <typename F, typename A> struct TileArgs {
   int nJT;        // X[DIR] / TJ
   int jtBegin;    // tiles along mu handled by this launch: [jtBegin, jtBegin + jtCount)
   int jtCount;
-  int tileBytes;  // LDS bytes of the staging tile (W follows it)
+  int tileBytes;  // LDS bytes of the two staging tiles
   int blockOrder; // workgroup -> tile map (see the kernel)
 };
 
@@ -178,14 +178,12 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
     colS = (col / ePR) * ePR + (xs >> 1);        // same row, entry x0' / 2
   }
 
-  // W_k(x) of this wave's (position, slot) for the 32 lines lives in LDS behind the tile ([9][32] per wave, read by both
-  // lane halves): registers are the scarce resource here, LDS bandwidth is not
-  // ... except where the registers allow it: fp32 storage (the stage registers are half as wide) and the fp64 row tile
-  // keep W_k in VGPRs and save 9 of the 27 LDS reads per eigenvector (measured -7 % / -9 % fp32, -3 % fp64 row tile; the
-  // fp64 column tile spills with W in registers and gets 35 % slower)
-  constexpr bool kWReg = sizeof(F) == 4 || DIR == 0;
+  // W_k(x) of this lane's site (both lane halves hold the same 3x3): in VGPRs.  It used to sit in LDS (9 of the 27 LDS
+  // reads per eigenvector) because the registers were short; fp32 storage has the room (stage registers half as wide:
+  // -7 % / -9 % per entry), fp64 gets it by prefetching two eigenvectors ahead instead of three (the kernel is bound by
+  // vector issue, not by memory latency: -3.6 % column, -2 % row tile; three-deep AND W in registers spills, +35 %).
   Cplx<A> Wr[9];
-  if constexpr (kWReg) {
+  {
     const Cplx<F> *e = reinterpret_cast<const Cplx<F> *>(a.E[slot]) + (int64_t)pmine * 12 * a.volumeCB + xmine;
 #pragma unroll
     for (int j = 0; j < 3; j++)
@@ -193,17 +191,6 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
       for (int i = 0; i < 3; i++) {
         const Cplx<F> t = e[(int64_t)(j * 3 + i) * a.volumeCB];
         Wr[i * 3 + j] = Cplx<A>{(A)t.re, (A)t.im};
-      }
-  }
-  Cplx<A> *Wl = reinterpret_cast<Cplx<A> *>(smem + a.tileBytes) + wave * 9 * kTileCols + col;
-  if (half == 0) {
-    const Cplx<F> *e = reinterpret_cast<const Cplx<F> *>(a.E[slot]) + (int64_t)pmine * 12 * a.volumeCB + xmine;
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const Cplx<F> t = e[(int64_t)(j * 3 + i) * a.volumeCB];
-        Wl[(i * 3 + j) * kTileCols] = Cplx<A>{(A)t.re, (A)t.im};
       }
   }
   Cplx<A> acc[8];  // acc[be*2 + a2], al = 2*half + a2
@@ -219,6 +206,7 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
   // change), column groups as the fastest workgroup index (4 % slower).
   const Cplx<F> *body0 = static_cast<const Cplx<F> *>(a.L[0]);
   (void)body0;
+  constexpr int kDepth = sizeof(F) == 8 ? 2 : 3;  // eigenvectors in flight ahead of the one being consumed
   vec2 stageA[PH], stageB[PH], stageC[PH];
   // fetch this lane's share of eigenvector n_: plane `wave`, column `col`, positions pp = 2*i + half
 #if defined(MUGIQ_TILE_EXPERIMENT) && MUGIQ_TILE_EXPERIMENT == 4 /* diagnostic: no table look-ups (contiguous fields) */
@@ -270,7 +258,7 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
     const Cplx<F> *bodyNow = bodyPre;                                                                                  \
     { /* table look-ups of the NEXT step, issued first: they complete while this step waits for its staged loads, and  \
          being scalar loads in flight they would otherwise turn the first LDS wait of the arithmetic into lgkmcnt(0) */ \
-      const int nb_ = (n_) + 5 < a.nVec ? (n_) + 5 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1;      \
+      const int nb_ = (n_) + kDepth + 2 < a.nVec ? (n_) + kDepth + 2 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1; \
       bodyPre = MUGIQ_TILE_BODY(nb_);                                                                                  \
       sigPre = MUGIQ_TILE_SIGMA(ns_);                                                                                  \
     }                                                                                                                  \
@@ -280,7 +268,7 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
       _Pragma("unroll") for (int i = 0; i < PH; i++)                                                                   \
         nxt[((2 * i + half) * 12 + wave) * kTileCols + col] = Cplx<F>{stage[i].x, stage[i].y};                         \
     }                                                                                                                  \
-    if (GUARD == 0 || (n_) + 4 < a.nVec) MUGIQ_TILE_FETCH_AT(bodyNow, (n_) + 4, stage)                                 \
+    if (GUARD == 0 || (n_) + kDepth + 1 < a.nVec) MUGIQ_TILE_FETCH_AT(bodyNow, (n_) + kDepth + 1, stage)               \
     if (computes) {                                                                                                    \
       const Cplx<F> *tl = tile + (ppL * 12) * kTileCols + col;                                                         \
       const Cplx<F> *ts = tile + (ppS * 12 + half * 6) * kTileCols + colS; /* spins 2*half, 2*half + 1 */              \
@@ -291,7 +279,7 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
         const Cplx<F> w0 = ts[j * kTileCols], w1 = ts[(3 + j) * kTileCols];                                            \
         const Cplx<A> p0j{(A)w0.re, (A)w0.im}, p1j{(A)w1.re, (A)w1.im};                                                \
         _Pragma("unroll") for (int i = 0; i < 3; i++) {                                                                \
-          const Cplx<A> w = kWReg ? Wr[i * 3 + j] : Wl[(i * 3 + j) * kTileCols];                                       \
+          const Cplx<A> w = Wr[i * 3 + j];                                                                             \
           cmadd(t0[i], w, p0j);                                                                                        \
           cmadd(t1[i], w, p1j);                                                                                        \
         }                                                                                                              \
@@ -324,23 +312,24 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
     const int last = a.nVec - 1;
     MUGIQ_TILE_FETCH((1 < last ? 1 : last), stageA)
     MUGIQ_TILE_FETCH((2 < last ? 2 : last), stageB)
-    MUGIQ_TILE_FETCH((3 < last ? 3 : last), stageC)
+    if constexpr (kDepth == 3) MUGIQ_TILE_FETCH((3 < last ? 3 : last), stageC)
   }
-  const Cplx<F> *bodyPre = MUGIQ_TILE_BODY(a.nVec > 4 ? 4 : a.nVec - 1);
+  const Cplx<F> *bodyPre = MUGIQ_TILE_BODY(a.nVec > kDepth + 1 ? kDepth + 1 : a.nVec - 1);
   A sigPre = MUGIQ_TILE_SIGMA(0);
   MUGIQ_LDS_BARRIER()
   // steady state without any data-dependent branch (hipcc's wait-count pass turns every conditional load into a
   // conservative `vmcnt(0)`, which would serialise the prefetch), then a guarded tail
   int n = 0;
-  for (; n + 6 < a.nVec; n += 3) {
+  for (; n + 2 * kDepth < a.nVec; n += kDepth) {
     MUGIQ_TILE_STEP(n, stageA, 0)
     MUGIQ_TILE_STEP(n + 1, stageB, 0)
-    MUGIQ_TILE_STEP(n + 2, stageC, 0)
+    if constexpr (kDepth == 3) MUGIQ_TILE_STEP(n + 2, stageC, 0)
   }
-  for (; n < a.nVec; n += 3) {
+  for (; n < a.nVec; n += kDepth) {
     MUGIQ_TILE_STEP(n, stageA, 1)
     if (n + 1 < a.nVec) MUGIQ_TILE_STEP(n + 1, stageB, 1)
-    if (n + 2 < a.nVec) MUGIQ_TILE_STEP(n + 2, stageC, 1)
+    if constexpr (kDepth == 3)
+      if (n + 2 < a.nVec) MUGIQ_TILE_STEP(n + 2, stageC, 1)
   }
 #undef MUGIQ_TILE_STEP
   // ---- epilogue: the two lane halves of a wave hold complementary halves of the 4x4 colour-traced spin matrix of the
@@ -377,7 +366,7 @@ template <typename F, typename A, int ORDER> static int launch_tile(TileArgs<F, 
   const int NP = dir >= 1 ? kTileTJ + a.kmax : kTileTJ;
   const int PHsel = NP <= 8 ? 4 : kTileMaxPos / 2;
   const size_t tileBytes = 2 * sizeof(Cplx<F>) * (size_t)(2 * PHsel) * 12 * kTileCols;  // two buffers, padded positions
-  const size_t shmem = tileBytes + sizeof(Cplx<A>) * 12 * 9 * kTileCols;     // tiles + W
+  const size_t shmem = tileBytes;  // the two staging tiles
   a.tileBytes = (int)tileBytes;
   unsigned nblocks = ((a.numCols + kTileCols - 1) / kTileCols) * a.jtCount;
   if (dir == 0) {  // row tile: 2 groups of kTileCols/(X0/2) whole x-rows per workgroup
@@ -428,7 +417,7 @@ bool tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int preci
   if (kmax > ev.X[dir]) return false;  // the staged window wraps at most once around the lattice
   if (kTileTJ + kmax > kTileMaxPos) return false;
   const int PHsel = kTileTJ + kmax <= 8 ? 4 : kTileMaxPos / 2;
-  const size_t lds = (size_t)2 * 2 * precision * (2 * PHsel) * 12 * kTileCols + (size_t)16 * 12 * 9 * kTileCols;
+  const size_t lds = (size_t)2 * 2 * precision * (2 * PHsel) * 12 * kTileCols;
   return lds <= 160 * 1024;
 }
 
