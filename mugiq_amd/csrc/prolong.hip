@@ -16,6 +16,8 @@
 // written: the ultra-local loop of the MG path costs one pass over V instead of N_ev fine-vector writes + reads.
 #include "internal.h"
 
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace mugiq {
@@ -259,6 +261,305 @@ static int launch_prolong(const MugiqHipTransfer *T, const MugiqHipCoarseField *
   return MUGIQ_HIP_SUCCESS;
 }
 
+
+// ---- MG ultra-local loop through the coarse-grid outer product -----------------------------------------------------
+// With psi_n(x) = V(x) phi_n(X(x)) the weighted sum over the eigenvectors can be taken on the COARSE grid first:
+//     sum_n s_n psi_n(x) psi_n(x)^dagger = V(x) C(X) V(x)^dagger,     C(X) = sum_n s_n phi_n(X) phi_n(X)^dagger,
+// one (2 n_vec)^2 Hermitian matrix per aggregate, shared by all its fine sites.  The N_ev-fold prolongation
+// (N_ev * 336 complex multiply-adds per fine site) becomes one congruence per fine site (about 15 000, independent of
+// N_ev): 4.5 x fewer flops at N_ev = 200, n_vec = 24, and the eigenvectors are read once from the 3 MB coarse fields.
+// The colour-traced spin matrix the gamma traces need is resG[be][al] = sum_c M[(al,c),(be,c)] with M = V C V^dagger
+// (lib/mugiq_contract_kernels.cu:98-105 with vL = vR = psi_n, summed over n with weights 1/sigma_n).
+template <typename F, typename A> struct CoarseOuterArgs {
+  const void *const *coarse;  // device table: nVec coarse bodies [parity][chi*NV + j][x_cb_c]
+  const A *inv_sigma;
+  int nVec, NV, volumeCBc, Cstride;
+  int64_t Cpo;
+  Cplx<A> *C;                 // [2*volumeCBc][NC][NC]
+};
+
+constexpr int kCoEvecs = 8;   // eigenvectors staged per barrier
+constexpr int kCoMaxNC = 64;  // 2 * n_vec handled by the coarse path
+
+// One workgroup per coarse site; the 256 threads tile C as 16 x 16 blocks of B x B entries (B = ceil(NC / 16)), so a
+// thread reads 2B components from LDS per B^2 complex multiply-adds.
+template <typename F, typename A, int B> __global__ __launch_bounds__(256) void coarse_outer_kernel(CoarseOuterArgs<F, A> a) {
+  __shared__ Cplx<A> ph[kCoEvecs][kCoMaxNC], phs[kCoEvecs][kCoMaxNC];
+  const int NC = 2 * a.NV;
+  const int pty = blockIdx.x / a.volumeCBc, x_cb = blockIdx.x - pty * a.volumeCBc;
+  const int r0 = (threadIdx.x >> 4) * B, c0 = (threadIdx.x & 15) * B;
+  Cplx<A> acc[B][B];
+#pragma unroll
+  for (int i = 0; i < B; i++)
+#pragma unroll
+    for (int j = 0; j < B; j++) acc[i][j] = Cplx<A>{A(0), A(0)};
+  for (int n0 = 0; n0 < a.nVec; n0 += kCoEvecs) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < kCoEvecs * kCoMaxNC; idx += 256) {
+      const int nn = idx / kCoMaxNC, comp = idx - nn * kCoMaxNC, n = n0 + nn;
+      Cplx<A> v{A(0), A(0)}, vs{A(0), A(0)};  // components beyond NC and eigenvectors beyond nVec contribute zero
+      if (n < a.nVec && comp < NC) {
+        typedef F vec2 __attribute__((ext_vector_type(2)));
+        const Cplx<F> *c = static_cast<const Cplx<F> *>(as_constant(a.coarse)[n]) + (int64_t)pty * a.Cpo + (int64_t)comp * a.Cstride + x_cb;
+        const vec2 u = *as_global(reinterpret_cast<const vec2 *>(c));
+        const A s = as_constant(a.inv_sigma)[n];
+        v = Cplx<A>{(A)u.x, (A)u.y};
+        vs = Cplx<A>{s * v.re, s * v.im};
+      }
+      ph[nn][comp] = v;
+      phs[nn][comp] = vs;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nn = 0; nn < kCoEvecs; nn++) {
+      Cplx<A> x[B], y[B];
+#pragma unroll
+      for (int i = 0; i < B; i++) {
+        x[i] = phs[nn][(r0 + i) & (kCoMaxNC - 1)];
+        y[i] = ph[nn][(c0 + i) & (kCoMaxNC - 1)];
+      }
+#pragma unroll
+      for (int i = 0; i < B; i++)
+#pragma unroll
+        for (int j = 0; j < B; j++) {  // acc += (s phi[r]) * conj(phi[c])
+          acc[i][j].re = fma(x[i].re, y[j].re, acc[i][j].re);
+          acc[i][j].re = fma(x[i].im, y[j].im, acc[i][j].re);
+          acc[i][j].im = fma(x[i].im, y[j].re, acc[i][j].im);
+          acc[i][j].im = fma(-x[i].re, y[j].im, acc[i][j].im);
+        }
+    }
+  }
+  Cplx<A> *out = a.C + (int64_t)blockIdx.x * NC * NC;
+#pragma unroll
+  for (int i = 0; i < B; i++)
+#pragma unroll
+    for (int j = 0; j < B; j++)
+      if (r0 + i < NC && c0 + j < NC) out[(r0 + i) * NC + c0 + j] = acc[i][j];
+}
+
+template <typename F, typename A> struct FineCongruenceArgs {
+  const Cplx<F> *V;       // [parity][(3s+c)*NV + j][x_cb]
+  int64_t Vpo;
+  int Vstride, NV;
+  int X[4], Xc[4], bs[4];
+  int volumeCB, volumeCBc, aggVol;
+  const Cplx<A> *C;       // [2*volumeCBc][NC][NC]
+  Cplx<A> *loop;          // [16][V]
+};
+
+// One workgroup per aggregate; SPR fine sites per round, 4 * NH lanes per site: lane (h, q) <-> column chunk h of JC null
+// vectors and (chi, chi') = (q >> 1, q & 1); it accumulates its share of the 2x2 block  sum_c M[(be,c),(al,c)],
+// be in {2chi, 2chi+1}, al in {2chi', 2chi'+1}.  C(X) sits in LDS for the whole workgroup; per round and colour the rows
+// V(x; :, c, :) of the SPR sites are staged in LDS.  T = u C is built for the lane's JC columns (2 rows x JC accumulators
+// in registers) and folded into the block at once; the NH partial blocks of a site are summed with wavefront shuffles.
+// (Spreading the chunks over lanes instead of looping over them doubles the waves per CU at the same LDS footprint.)
+template <typename F, typename A, int JC, int SPR, int NH>
+__global__ __launch_bounds__(4 * NH * SPR) void fine_congruence_kernel(FineCongruenceArgs<F, A> a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int NV = a.NV, NC = 2 * NV;
+  Cplx<A> *Cs = reinterpret_cast<Cplx<A> *>(smem);                                    // [NC][NC]
+  Cplx<A> *red = Cs + NC * NC;                                                         // [SPR][16]
+  Cplx<F> *Vs = reinterpret_cast<Cplx<F> *>(red + SPR * 16);                           // [4 spins][NV][SPR]
+  constexpr int LPS = 4 * NH, NT = LPS * SPR;  // lanes per site, threads per workgroup
+  const int t = threadIdx.x, sidx = t / LPS, lane = t % LPS, hh = lane >> 2, q = lane & 3, chi = q >> 1, chip = q & 1;
+
+  // the aggregate: blockIdx.x runs lexicographically over the coarse lattice
+  int cc[4], r = blockIdx.x;
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    cc[d] = r % a.Xc[d];
+    r /= a.Xc[d];
+  }
+  const int cpar = (cc[0] + cc[1] + cc[2] + cc[3]) & 1;
+  const Cplx<A> *Cg = a.C + ((int64_t)cpar * a.volumeCBc + (lex_index(cc, a.Xc) >> 1)) * (int64_t)(NC * NC);
+  for (int i = t; i < NC * NC; i += NT) Cs[i] = Cg[i];
+
+  // fine site (parity, x_cb) of aggregate member k (lexicographic inside the block); k >= aggVol shadows the last one
+  auto member = [&](int k, int &pty, int &x_cb) {
+    if (k >= a.aggVol) k = a.aggVol - 1;
+    int x[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      x[d] = cc[d] * a.bs[d] + k % a.bs[d];
+      k /= a.bs[d];
+    }
+    pty = (x[0] + x[1] + x[2] + x[3]) & 1;
+    x_cb = lex_index(x, a.X) >> 1;
+  };
+
+  const int rounds = (a.aggVol + SPR - 1) / SPR;
+  const int stSite = t % SPR, stRow0 = t / SPR;  // staging: this lane always fetches site stSite, rows stRow0 + LPS*i
+  for (int rd = 0; rd < rounds; rd++) {
+    int myP, myX, stP, stX;
+    member(rd * SPR + sidx, myP, myX);
+    member(rd * SPR + stSite, stP, stX);
+    Cplx<A> blk[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) blk[i][0] = blk[i][1] = Cplx<A>{A(0), A(0)};
+    for (int c = 0; c < 3; c++) {
+      __syncthreads();  // previous consumers of Vs (and the first use of Cs) are done / ready
+      for (int row = stRow0; row < 4 * NV; row += LPS) {  // row = spin * NV + j
+        const int sp = row / NV, j = row - sp * NV;
+        typedef F vec2 __attribute__((ext_vector_type(2)));
+        const Cplx<F> *src = a.V + (int64_t)stP * a.Vpo + (int64_t)((3 * sp + c) * NV + j) * a.Vstride + stX;
+        const vec2 u = *as_global(reinterpret_cast<const vec2 *>(src));
+        Vs[row * SPR + stSite] = Cplx<F>{u.x, u.y};
+      }
+      __syncthreads();
+      const Cplx<F> *u0p = Vs + (2 * chi) * NV * SPR + sidx, *u1p = u0p + NV * SPR;      // rows be = 2chi, 2chi+1
+      const Cplx<F> *w0p = Vs + (2 * chip) * NV * SPR + sidx, *w1p = w0p + NV * SPR;    // rows al = 2chi', 2chi'+1
+      {
+        const int h = hh * JC;
+        Cplx<A> T0[JC], T1[JC];
+#pragma unroll
+        for (int jj = 0; jj < JC; jj++) T0[jj] = T1[jj] = Cplx<A>{A(0), A(0)};
+        const Cplx<A> *crow = Cs + (chi * NV) * NC + chip * NV + h;
+        for (int j = 0; j < NV; j++) {
+          const Cplx<F> a0 = u0p[j * SPR], a1 = u1p[j * SPR];
+          const Cplx<A> u0{(A)a0.re, (A)a0.im}, u1{(A)a1.re, (A)a1.im};
+#pragma unroll
+          for (int jj = 0; jj < JC; jj++) {
+            const Cplx<A> cv = crow[j * NC + jj];
+            cmadd(T0[jj], u0, cv);
+            cmadd(T1[jj], u1, cv);
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < JC; jj++) {  // blk[b2][a2] += T_b2[j'] * conj(V[al, c, j'])
+          const Cplx<F> b0 = w0p[(h + jj) * SPR], b1 = w1p[(h + jj) * SPR];
+          const Cplx<A> w0{(A)b0.re, (A)b0.im}, w1{(A)b1.re, (A)b1.im};
+          cmadd_conj(blk[0][0], w0, T0[jj]);
+          cmadd_conj(blk[0][1], w1, T0[jj]);
+          cmadd_conj(blk[1][0], w0, T1[jj]);
+          cmadd_conj(blk[1][1], w1, T1[jj]);
+        }
+      }
+    }
+    // sum the NH column chunks (lanes q + 4h of the same site sit in one wavefront)
+#pragma unroll
+    for (int m = 4; m < LPS; m <<= 1)
+#pragma unroll
+      for (int b2 = 0; b2 < 2; b2++)
+#pragma unroll
+        for (int a2 = 0; a2 < 2; a2++) {
+          blk[b2][a2].re += __shfl_xor(blk[b2][a2].re, m);
+          blk[b2][a2].im += __shfl_xor(blk[b2][a2].im, m);
+        }
+    // resG[al][be] = sum_c M[(be,c),(al,c)]: collect the four 2x2 blocks of a site, then 4 of the 16 gamma traces per lane
+    if (hh == 0) {
+#pragma unroll
+      for (int b2 = 0; b2 < 2; b2++)
+#pragma unroll
+        for (int a2 = 0; a2 < 2; a2++) red[sidx * 16 + (2 * chip + a2) * 4 + (2 * chi + b2)] = blk[b2][a2];
+    }
+    __syncthreads();
+    if (hh == 0 && rd * SPR + sidx < a.aggVol) {
+      Cplx<A> full[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) full[i] = red[sidx * 16 + i];
+      const int site = myX + myP * a.volumeCB;
+      if (q == 0) trace_and_store_range<A, 0, 4>(a.loop, full, 2 * a.volumeCB, site);
+      else if (q == 1) trace_and_store_range<A, 4, 8>(a.loop, full, 2 * a.volumeCB, site);
+      else if (q == 2) trace_and_store_range<A, 8, 12>(a.loop, full, 2 * a.volumeCB, site);
+      else trace_and_store_range<A, 12, 16>(a.loop, full, 2 * a.volumeCB, site);
+    }
+  }
+}
+
+// LDS bytes of the congruence kernel; 0 if this (n_vec, precision) does not fit
+template <typename F, typename A> static size_t congruence_lds(int NV, int SPR) {
+  const size_t NC = 2 * (size_t)NV;
+  return sizeof(Cplx<A>) * (NC * NC + (size_t)SPR * 16) + sizeof(Cplx<F>) * 4 * NV * (size_t)SPR;
+}
+
+template <typename F, typename A, int JC, int SPR, int NH> static int launch_congruence(const FineCongruenceArgs<F, A> &a, size_t shmem, hipStream_t stream) {
+  auto kern = fine_congruence_kernel<F, A, JC, SPR, NH>;
+  if (shmem > 64 * 1024)
+    MUGIQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(kern, dim3(2 * a.volumeCBc), dim3(4 * NH * SPR), shmem, stream, a);
+  MUGIQ_CHECK_HIP(hipGetLastError());
+  return MUGIQ_HIP_SUCCESS;
+}
+
+// returns -1 if the coarse-grid plan does not apply (caller falls back to the per-eigenvector kernel)
+template <typename F, typename A>
+static int coarse_plan(const MugiqHipTransfer *T, const MugiqHipCoarseField *coarse, const double *sigma, void *loop_d, int nVec,
+                       hipStream_t stream) {
+  const int NV = T->nVec, NC = 2 * NV;
+  // supported shapes: n_vec = 8, 16, 32 (chunks of 8 columns) and 12, 24 (chunks of 12); NH = n_vec / chunk lanes per
+  // (site, chi, chi') must be a power of two (shuffle reduction) and 4 * NH * SPR <= 1024 threads
+  if (!(NV == 8 || NV == 16 || NV == 32 || NV == 12 || NV == 24)) return -1;
+  const int JC = NV % 12 == 0 ? 12 : 8, NH = NV / JC;  // (6-column chunks on 16 lanes per site measured 8 % slower)
+  int SPR = 64;
+  if (congruence_lds<F, A>(NV, SPR) > 150 * 1024 || 4 * NH * SPR > 1024) SPR = 32;
+  if (congruence_lds<F, A>(NV, SPR) > 150 * 1024) return -1;
+  long long volc = 1, aggVol = 1;
+  for (int d = 0; d < 4; d++) {
+    volc *= T->X[d] / T->geoBlockSize[d];
+    aggVol *= T->geoBlockSize[d];
+  }
+  const size_t pb = sizeof(void *) * (size_t)nVec;
+  const size_t tabBytes = (pb + sizeof(A) * (size_t)nVec + 255) / 256 * 256;
+  const size_t cBytes = sizeof(Cplx<A>) * (size_t)volc * NC * NC;
+  // one scratch region holds [pointer table | 1/sigma | C]: reserve it in full first, so that the table upload below
+  // (which draws on the same per-device scratch) cannot move it
+  void *base = nullptr;
+  int st = device_scratch(&base, tabBytes + cBytes);
+  if (st) return st;
+  std::vector<unsigned char> host(tabBytes, 0);
+  const void **hc = reinterpret_cast<const void **>(host.data());
+  A *hs = reinterpret_cast<A *>(host.data() + pb);
+  for (int n = 0; n < nVec; n++) {
+    hc[n] = coarse[n].data;
+    hs[n] = static_cast<A>(1.0 / static_cast<F>(sigma[n]));
+  }
+  void *dev = nullptr;
+  if ((st = upload_table(&dev, host.data(), tabBytes, stream))) return st;
+  MUGIQ_REQUIRE(dev == base, "prolongateContract: scratch moved under the coarse-grid plan");
+  CoarseOuterArgs<F, A> o;
+  o.coarse = reinterpret_cast<const void *const *>(dev);
+  o.inv_sigma = reinterpret_cast<const A *>(static_cast<unsigned char *>(dev) + pb);
+  o.nVec = nVec;
+  o.NV = NV;
+  o.volumeCBc = (int)(volc / 2);
+  o.Cstride = coarse[0].stride;
+  o.Cpo = coarse[0].parity_offset;
+  o.C = reinterpret_cast<Cplx<A> *>(static_cast<unsigned char *>(dev) + tabBytes);
+  switch ((NC + 15) / 16) {
+  case 1: hipLaunchKernelGGL((coarse_outer_kernel<F, A, 1>), dim3((unsigned)volc), dim3(256), 0, stream, o); break;
+  case 2: hipLaunchKernelGGL((coarse_outer_kernel<F, A, 2>), dim3((unsigned)volc), dim3(256), 0, stream, o); break;
+  case 3: hipLaunchKernelGGL((coarse_outer_kernel<F, A, 3>), dim3((unsigned)volc), dim3(256), 0, stream, o); break;
+  default: hipLaunchKernelGGL((coarse_outer_kernel<F, A, 4>), dim3((unsigned)volc), dim3(256), 0, stream, o); break;
+  }
+  MUGIQ_CHECK_HIP(hipGetLastError());
+
+  FineCongruenceArgs<F, A> a;
+  a.V = static_cast<const Cplx<F> *>(T->V);
+  a.Vpo = T->parity_offset;
+  a.Vstride = T->stride;
+  a.NV = NV;
+  long long vol = 1;
+  for (int d = 0; d < 4; d++) {
+    a.X[d] = T->X[d];
+    a.bs[d] = T->geoBlockSize[d];
+    a.Xc[d] = T->X[d] / T->geoBlockSize[d];
+    vol *= T->X[d];
+  }
+  a.volumeCB = (int)(vol / 2);
+  a.volumeCBc = (int)(volc / 2);
+  a.aggVol = (int)aggVol;
+  a.C = o.C;
+  a.loop = static_cast<Cplx<A> *>(loop_d);
+  const size_t shmem = congruence_lds<F, A>(NV, SPR);
+#define MUGIQ_CONGRUENCE_CASE(J, S, H) \
+  if (JC == J && SPR == S && NH == H) return launch_congruence<F, A, J, S, H>(a, shmem, stream);
+  MUGIQ_CONGRUENCE_CASE(12, 64, 2) MUGIQ_CONGRUENCE_CASE(12, 32, 2) MUGIQ_CONGRUENCE_CASE(12, 64, 1) MUGIQ_CONGRUENCE_CASE(12, 32, 1)
+  MUGIQ_CONGRUENCE_CASE(8, 64, 1) MUGIQ_CONGRUENCE_CASE(8, 32, 1) MUGIQ_CONGRUENCE_CASE(8, 64, 2) MUGIQ_CONGRUENCE_CASE(8, 32, 2)
+  MUGIQ_CONGRUENCE_CASE(8, 64, 4) MUGIQ_CONGRUENCE_CASE(8, 32, 4)
+#undef MUGIQ_CONGRUENCE_CASE
+  return -1;
+}
+
 }  // namespace mugiq
 
 using namespace mugiq;
@@ -302,6 +603,15 @@ int mugiq_hip_prolongate_contract_batched(void *loopData_d, int loopPrecision, c
   if (loopPrecision == 0) loopPrecision = p;
   MUGIQ_REQUIRE(loopPrecision == p || (loopPrecision == 8 && p == 4), "%s: loop precision %d with field precision %d is not supported", who, loopPrecision, p);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // MUGIQ_HIP_MG_PLAN=direct keeps the per-eigenvector kernel (prolong every eigenvector, contract on the spot)
+  const char *plan = getenv("MUGIQ_HIP_MG_PLAN");
+  if (!(plan && strcmp(plan, "direct") == 0)) {
+    int rc;
+    if (p == 8) rc = coarse_plan<double, double>(transfer, coarse_h, sigma_h, loopData_d, nVec, s);
+    else if (loopPrecision == 8) rc = coarse_plan<float, double>(transfer, coarse_h, sigma_h, loopData_d, nVec, s);
+    else rc = coarse_plan<float, float>(transfer, coarse_h, sigma_h, loopData_d, nVec, s);
+    if (rc >= 0) return rc;
+  }
   if (p == 8) return launch_prolong<double, double, 2, false, true>(transfer, coarse_h, nullptr, sigma_h, loopData_d, nVec, s);
   if (loopPrecision == 8) return launch_prolong<float, double, 2, false, true>(transfer, coarse_h, nullptr, sigma_h, loopData_d, nVec, s);
   return launch_prolong<float, float, 2, false, true>(transfer, coarse_h, nullptr, sigma_h, loopData_d, nVec, s);

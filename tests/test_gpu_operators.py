@@ -360,10 +360,19 @@ def test_prolongator_matches_oracle(hip, prec, order, X, bs, nvec, nev):
         assert rel_err(ff[n].get_logical(), exp) < (1e-14 if prec == 8 else 2e-6), n
 
 
+@pytest.mark.parametrize("plan", ["coarse", "direct"])
 @pytest.mark.parametrize("prec,lprec", [(8, 8), (4, 4), (4, 8)])
-@pytest.mark.parametrize("X,bs,nvec,nev", [((8, 8, 8, 8), (4, 4, 4, 4), 24, 37), ((4, 4, 4, 6), (2, 2, 2, 1), 3, 2)])
-def test_fused_prolong_contract_matches_oracle(hip, prec, lprec, X, bs, nvec, nev):
-    """MG ultra-local loop: (P c_n)^dag G (P c_n) summed over n, fine vectors never written."""
+@pytest.mark.parametrize("X,bs,nvec,nev", [((8, 8, 8, 8), (4, 4, 4, 4), 24, 37), ((4, 4, 4, 6), (2, 2, 2, 1), 3, 2),
+                                           ((4, 4, 4, 4), (2, 2, 2, 2), 32, 9), ((8, 8, 4, 4), (4, 4, 2, 2), 12, 5),
+                                           ((8, 4, 12, 4), (2, 2, 3, 2), 16, 11), ((4, 8, 4, 4), (2, 4, 2, 1), 8, 3)])
+def test_fused_prolong_contract_matches_oracle(hip, prec, lprec, X, bs, nvec, nev, plan, monkeypatch):
+    """MG ultra-local loop: (P c_n)^dag G (P c_n) summed over n, fine vectors never written.  Two plans behind one entry
+    point: "coarse" = outer product of the eigenvectors on the coarse grid + one congruence per fine site (n_vec 8, 12,
+    16, 24, 32), "direct" = prolong every eigenvector and contract on the spot (any n_vec; the fallback)."""
+    if plan == "direct":
+        monkeypatch.setenv("MUGIQ_HIP_MG_PLAN", "direct")
+    else:
+        monkeypatch.delenv("MUGIQ_HIP_MG_PLAN", raising=False)
     V, phis, Xc = _mg_problem(X, bs, nvec, nev, 72)
     cdt = _np_c(prec)
     V = V.astype(cdt)
