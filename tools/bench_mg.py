@@ -49,7 +49,9 @@ def timeit(fn):
 
 flops = 8.0 * 12 * a.nvec * V * a.nev                     # complex MACs of P
 ms = timeit(lambda: (loop.zero_(), hip.prolongateContractBatched(loop, cf, sig, T)))
-res["fused_prolong_contract"] = {"ms": ms, "sites_per_s": V / ms * 1e3, "prolong_TFLOPs": flops / ms / 1e9}
+res["fused_prolong_contract"] = {"ms": ms, "sites_per_s": V / ms * 1e3, "plan": os.environ.get("MUGIQ_HIP_MG_PLAN", "coarse"),
+                                 # flops of the per-eigenvector algorithm divided by the time: comparable across plans, not a hardware rate
+                                 "per_eigenvector_algorithm_TFLOPs_equivalent": flops / ms / 1e9}
 if a.write_fine:
     big = torch.empty(a.nev * 24 * (V // 2), dtype=cdt, device="cuda")
     ff = [hip.SpinorField(X, a.precision, 2, data=big[n * 24 * (V // 2):(n + 1) * 24 * (V // 2)]) for n in range(a.nev)]
