@@ -427,14 +427,15 @@ def test_random_geometry_contraction_and_prolongator(hip, seed):
 
     # prolongator: aggregates that divide X into even coarse extents
     bs = tuple(int(rng.choice([b for b in (1, 2, 3, 4, 6) if X[d] % b == 0 and (X[d] // b) % 2 == 0])) for d in range(4))
-    nvec = int(rng.choice([1, 2, 3, 5, 8, 24, 32]))
+    nvec = int(rng.choice([1, 2, 3, 5, 8, 12, 16, 24, 32]))
     ncv = int(rng.integers(1, 40))
     Vn, phis, Xc = _mg_problem(X, bs, nvec, ncv, 6000 + seed)
     cdt = _np_c(prec)
     Vn = Vn.astype(cdt)
     phis = [q.astype(cdt) for q in phis]
-    T = hip.Transfer(X, nvec, bs, 2, prec).set_logical(Vn)
-    cf = [hip.CoarseField(Xc, nvec, prec).set_logical(q) for q in phis]
+    vpad, cpad = int(rng.choice([0, 0, 4, 30])), int(rng.choice([0, 0, 2, 10]))          # padded strides of V and of the coarse fields
+    T = hip.Transfer(X, nvec, bs, 2, prec, pad=vpad).set_logical(Vn)
+    cf = [hip.CoarseField(Xc, nvec, prec, pad=cpad).set_logical(q) for q in phis]
     ff = [hip.SpinorField(X, prec, order, pad=pad) for _ in range(ncv)]
     hip.prolongateEvecs(ff, cf, T)
     sg2 = sigmas(ncv)
