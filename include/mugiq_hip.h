@@ -167,6 +167,24 @@ int mugiq_hip_pack_face(void *face_d, const MugiqHipSpinorField *src, int dim, i
 int mugiq_hip_pack_face_layers(void *faces_d, const MugiqHipSpinorField *eVecs_h, int nVec, int dim, int high,
                                int layers, void *stream);
 
+/* ---- reflected displacement entries (new) ----------------------------------------------------------------------
+ * The reference computes the "+mu" and "-mu" entries of a displacement independently (lib/loop_mugiq.cpp:478-500).
+ * Because W_{-k}(x) = W_{+k}(x - k mu)^dagger, gamma matrices commute with colour matrices and sigma_n is real,
+ *     L^-_{k,G}(x) = eta_G conj( L^+_{k,G}(x - k mu) ),   L^+_{k,G}(x) = eta_G conj( L^-_{k,G}(x + k mu) ),
+ * eta_G = +-1 with G^dagger = eta_G G.  dstSlot_d / srcSlot_d: one loop slot each (16*V complex of `precision`, the
+ * dataPos layout loopData[tid + V*iG]); dstDispSign = sign of the entry being derived; length = k.  If
+ * commDim[dispDir] != 0, ghostLayers_d holds the k boundary layers of the neighbour's source slot as
+ * mugiq_hip_pack_loop_layers writes them (dst "-": the backward neighbour's HIGH layers; dst "+": the forward
+ * neighbour's LOW layers). */
+int mugiq_hip_reflect_displaced_loop(void *dstSlot_d, const void *srcSlot_d, const void *ghostLayers_d, const int localL[4],
+                                     int dispDir, int dstDispSign, int length, const int commDim[4], int precision,
+                                     void *stream);
+
+/* layers_d[((j*16 + iG)*2 + parity)*faceCB + ghostFaceIndex] = slot value at x[dim] = X[dim]-layers+j (high = 1) or
+ * x[dim] = j (high = 0), j < layers: 32*layers*faceCB complex of `precision`. */
+int mugiq_hip_pack_loop_layers(void *layers_d, const void *slot_d, const int localL[4], int dim, int high, int layers,
+                               int precision, void *stream);
+
 /* ---- fused displaced contraction (new; the fast form of lib/loop_mugiq.cpp:485-497) --------------------------- */
 /* For one displacement entry (dispDir, dispSign) and the lengths kValues_h[0..nK):
  *   loopData_d[slot i][tid + V*iG] += sum_n (1/sigma_n) v_n^dag(x) G(iG) W_k(x) v_n(x +- k mu),  k = kValues_h[i]
@@ -359,6 +377,9 @@ int mugiq_hip_loop_compute(MugiqHipLoop *loop);
 int mugiq_hip_loop_get_info(const MugiqHipLoop *loop, MugiqHipLoopInfo *info);
 /* slot bookkeeping of entry id: (dir, sign, start, stop, nLoopPerEntry, nLoopOffset) -> out6[6] */
 int mugiq_hip_loop_get_entry(const MugiqHipLoop *loop, int id, int out6[6]);
+/* After mugiq_hip_loop_compute: the entry that entry `id` was reflected from (see mugiq_hip_reflect_displaced_loop), or
+ * -1 if it was computed from the eigenvectors; -2 for a bad handle / index. */
+int mugiq_hip_loop_entry_derived_from(const MugiqHipLoop *loop, int id);
 /* dataPos_d: [nLoop][16][V even-odd] complex, device.  dataPos (host) is copied on first request
  * (the reference copies it unconditionally at lib/loop_mugiq.cpp:512). */
 const void *mugiq_hip_loop_data_pos_d(const MugiqHipLoop *loop);

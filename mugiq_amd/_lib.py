@@ -90,6 +90,8 @@ SIGNATURES = {
     "mugiq_hip_momentum_projection": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_longlong,
                                                      ctypes.c_int, ctypes.c_int, _VP, ctypes.c_size_t, _VP]),
     "mugiq_hip_pack_face_layers": (ctypes.c_int, [_VP, _SP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP]),
+    "mugiq_hip_reflect_displaced_loop": (ctypes.c_int, [_VP, _VP, _VP, _I4, ctypes.c_int, ctypes.c_int, ctypes.c_int, _I4, ctypes.c_int, _VP]),
+    "mugiq_hip_pack_loop_layers": (ctypes.c_int, [_VP, _VP, _I4, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP]),
     "mugiq_hip_displaced_loop_contraction_fused": (ctypes.c_int, [_VP, _SP, ctypes.POINTER(ctypes.c_double), ctypes.c_int,
                                                                   ctypes.POINTER(ctypes.c_void_p), _I4, ctypes.c_int,
                                                                   ctypes.c_int, ctypes.c_int, _I4, _VP, ctypes.c_int, _VP]),
@@ -105,6 +107,7 @@ SIGNATURES = {
     "mugiq_hip_loop_compute": (ctypes.c_int, [_VP]),
     "mugiq_hip_loop_get_info": (ctypes.c_int, [_VP, _VP]),
     "mugiq_hip_loop_get_entry": (ctypes.c_int, [_VP, ctypes.c_int, _I4]),
+    "mugiq_hip_loop_entry_derived_from": (ctypes.c_int, [_VP, ctypes.c_int]),
     "mugiq_hip_loop_data_pos_d": (_VP, [_VP]),
     "mugiq_hip_loop_data_pos_h": (_VP, [_VP]),
     "mugiq_hip_loop_data_mom_bcast_h": (_VP, [_VP]),

@@ -48,6 +48,7 @@ struct MugiqHipLoop_s {
   long long locV4 = 1, locV3 = 1, totV3 = 1;
   std::vector<std::string> dispEntry, dispString;
   std::vector<int> dispStart, dispStop, nLoopPerEntry, nLoopOffset, dispDir, dispSign;
+  std::vector<int> derivedFrom;  // per entry: the entry it was reflected from in the last compute, or -1
   int nDispEntries = 0, nLoop = 0, nData = 0;
   std::string fnameMom, fnamePos;
   bool writeMom = false, writePos = false;
@@ -262,6 +263,48 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
   return MUGIQ_HIP_SUCCESS;
 }
 
+// Reflected entries (csrc/reflect.hip): entry `id` can be derived from an entry `jd` computed earlier in this run if jd
+// has the same direction, the opposite sign and covers id's lengths.  Returns the source entry or -1.
+static int reflection_source(const MugiqHipLoop *lp, int id) {
+  if (const char *e = getenv("MUGIQ_HIP_REFLECT"))
+    if (atoi(e) == 0) return -1;
+  for (int jd = 0; jd < id; jd++)
+    if (lp->dispDir[jd] == lp->dispDir[id] && lp->dispSign[jd] != lp->dispSign[id] && lp->dispStart[jd] <= lp->dispStart[id] &&
+        lp->dispStop[id] <= lp->dispStop[jd] && lp->derivedFrom[jd] < 0)
+      return jd;
+  return -1;
+}
+
+static int entry_reflected(MugiqHipLoop *lp, int id, int jd, void *slot0) {
+  const int dir = lp->dispDir[id], sign = lp->dispSign[id];
+  const bool part = lp->commDim[dir] != 0;
+  const size_t slotBytes = (size_t)lp->nElemPosLocPerLoop * lp->loopBytes();
+  const char *src0 = static_cast<const char *>(lp->dataPos_d) + slotBytes * (size_t)lp->nLoopOffset[jd];
+  const int faceCB = lp->volumeCB / lp->localL[dir];
+  int st;
+  for (int k = lp->dispStart[id]; k <= lp->dispStop[id]; k++) {
+    void *dst = static_cast<char *>(slot0) + slotBytes * (size_t)(k - lp->dispStart[id]);
+    const void *src = src0 + slotBytes * (size_t)(k - lp->dispStart[jd]);
+    void *grecv = nullptr;
+    if (part) {
+      if (k > lp->localL[dir]) return -1;  // reaches past the nearest neighbour: let the caller compute the entry
+      // dst "-": the source sites x - k mu below my block are the backward neighbour's top k layers, so every rank sends its
+      // top layers forward; dst "+": bottom layers backward
+      const int high = sign == MUGIQ_HIP_DISP_SIGN_MINUS ? 1 : 0;
+      const size_t bytes = (size_t)32 * k * faceCB * lp->loopBytes();
+      void *gsend = nullptr;
+      if ((st = scratch_alloc(lp, &gsend, bytes, false))) return st;
+      if ((st = scratch_alloc(lp, &grecv, bytes, false))) return st;
+      if ((st = mugiq_hip_pack_loop_layers(gsend, src, lp->localL, dir, high, k, lp->loopPrecision, lp->stream))) return st;
+      st = lp->comm.sendrecv(lp->comm.ctx, gsend, grecv, bytes, dir, high ? +1 : -1, lp->stream);
+      if (st) return set_error(MUGIQ_HIP_ERROR_HIP, "halo sendrecv callback failed with status %d", st);
+    }
+    if ((st = mugiq_hip_reflect_displaced_loop(dst, src, grecv, lp->localL, dir, sign, k, lp->commDim, lp->loopPrecision, lp->stream)))
+      return st;
+  }
+  return MUGIQ_HIP_SUCCESS;
+}
+
 // hand the current entry's buffers back to the pool (the stream has been synchronised by the caller)
 static void free_scratch(MugiqHipLoop *lp) {
   for (void *p : lp->scratch)
@@ -459,6 +502,7 @@ int mugiq_hip_loop_create(MugiqHipLoop **out, const MugiqHipLoopParam *p, const 
       if ((st = parse_displacement(lp->dispString[id].c_str(), &dir, &sign))) return fail(st);  // Displace::setupDisplacement
       lp->dispDir.push_back(dir);
       lp->dispSign.push_back(sign);
+      lp->derivedFrom.push_back(-1);
     }
     lp->nLoop += 1;  // Don't forget ultra-local case!!
     if (lp->nDispEntries > 0) {
@@ -602,7 +646,20 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
                                                               lp->sigma.data(), lp->nEv, lp->stream);
       }
     } else {
-      st = basic ? entry_basic(lp, id, slot0) : entry_fused(lp, id, slot0);
+      lp->derivedFrom[id] = -1;
+      int done = 0;
+      if (!basic) {  // the OPT plan derives a "-mu" entry from the "+mu" entry of the same lengths (or vice versa)
+        const int jd = reflection_source(lp, id);
+        if (jd >= 0) {
+          st = entry_reflected(lp, id, jd, slot0);
+          if (st == -1) st = MUGIQ_HIP_SUCCESS;  // not derivable after all (length beyond the neighbour): compute it
+          else {
+            done = 1;
+            lp->derivedFrom[id] = jd;
+          }
+        }
+      }
+      if (!done) st = basic ? entry_basic(lp, id, slot0) : entry_fused(lp, id, slot0);
       hipError_t e = hipStreamSynchronize(lp->stream);
       free_scratch(lp);
       if (!st && e != hipSuccess) st = set_error(MUGIQ_HIP_ERROR_HIP, "computeCoarseLoop: %s", hipGetErrorString(e));
@@ -654,6 +711,11 @@ int mugiq_hip_loop_get_entry(const MugiqHipLoop *lp, int id, int out6[6]) {
   out6[4] = lp->nLoopPerEntry[id];
   out6[5] = lp->nLoopOffset[id];
   return MUGIQ_HIP_SUCCESS;
+}
+
+int mugiq_hip_loop_entry_derived_from(const MugiqHipLoop *lp, int id) {
+  if (!lp || id < 0 || id >= lp->nDispEntries) return -2;
+  return lp->derivedFrom[id];
 }
 
 const void *mugiq_hip_loop_data_pos_d(const MugiqHipLoop *lp) { return lp ? lp->dataPos_d : nullptr; }

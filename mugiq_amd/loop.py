@@ -173,6 +173,11 @@ class Loop_Mugiq:
         _lib.check(_lib.load().mugiq_hip_loop_get_entry(self._handle, idx, out))
         return tuple(out)
 
+    def derivedFrom(self, idx):
+        """After computeCoarseLoop: the entry that entry `idx` was reflected from (opposite sign, same direction and
+        lengths), or -1 if it was computed from the eigenvectors."""
+        return int(_lib.load().mugiq_hip_loop_entry_derived_from(self._handle, int(idx)))
+
     def computeCoarseLoop(self):
         """lib/loop_mugiq.cpp:439-525"""
         _lib.check(_lib.load().mugiq_hip_loop_compute(self._handle))

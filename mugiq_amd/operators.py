@@ -128,6 +128,26 @@ def packFaceLayers(faces_d, eVecs, dim, high, layers):
     _lib.check(_lib.load().mugiq_hip_pack_face_layers(faces_d.data_ptr(), d, len(eVecs), int(dim), int(high), int(layers), _stream()))
 
 
+def reflectDisplacedLoop(dstSlot_d, srcSlot_d, localL, dispDir, dstDispSign, length, commDim=(0, 0, 0, 0), ghostLayers_d=None):
+    """dst slot = eta_G conj(src slot shifted by -+length along dispDir): the entry of the opposite sign (see mugiq_hip.h)."""
+    V = int(np.prod(localL))
+    assert dstSlot_d.numel() >= 16 * V and srcSlot_d.numel() >= 16 * V and dstSlot_d.dtype == srcSlot_d.dtype
+    L = (ctypes.c_int * 4)(*[int(x) for x in localL])
+    cd = (ctypes.c_int * 4)(*[int(x) for x in commDim])
+    _lib.check(_lib.load().mugiq_hip_reflect_displaced_loop(
+        dstSlot_d.data_ptr(), srcSlot_d.data_ptr(), ghostLayers_d.data_ptr() if ghostLayers_d is not None else None, L,
+        int(dispDir), int(dstDispSign), int(length), cd, _prec_of(srcSlot_d), _stream()))
+
+
+def packLoopLayers(layers_d, slot_d, localL, dim, high, layers):
+    """The `layers` boundary layers of one loop slot, as reflectDisplacedLoop expects its ghost layers."""
+    V = int(np.prod(localL))
+    assert layers_d.numel() >= 32 * layers * (V // 2 // localL[dim]) and layers_d.dtype == slot_d.dtype
+    L = (ctypes.c_int * 4)(*[int(x) for x in localL])
+    _lib.check(_lib.load().mugiq_hip_pack_loop_layers(layers_d.data_ptr(), slot_d.data_ptr(), L, int(dim), int(high), int(layers),
+                                                      _prec_of(slot_d), _stream()))
+
+
 def displacedLoopContractionFused(loopData_d, eVecs, sigmas, pathLinkFields, kValues, dispDir, dispSign,
                                   commDim=(0, 0, 0, 0), ghostLayers_d=None, layers=0):
     """loop slot i += sum_n (1/sigma_n) v_n^dag G W_k v_n(x +- k mu), k = kValues[i] (see mugiq_hip.h)."""

@@ -326,3 +326,28 @@ def test_driver_random_shapes_both_fused_plans(hip, seed, monkeypatch):
         err_mom = rel_err(loop.dataMom_bcast, ref_mom)
         loop.close()
         assert err < tol and err_mom < tol, (X, prec, order, nev, entry, pad, gpad, tile, err, err_mom)
+
+
+def test_driver_reflects_opposite_sign_entries(hip, monkeypatch):
+    """OPT plan: an entry whose direction and lengths were already computed with the opposite sign is derived from it
+    (csrc/reflect.hip) instead of going through the eigenvectors again; MUGIQ_HIP_REFLECT=0 and the BASIC plan compute
+    every entry.  All of them agree with the oracle."""
+    X = (4, 8, 4, 8)
+    nev = 3
+    ev, Uo, f, U = _setup(hip, X, nev, 8, 2, 555)
+    sg = sigmas(nev)
+    entry = "+t:1,3;-t:1,3;-y:2,4;+y:3;+x:1,2;-x:1,3;-z:1;+z:1"
+    _, s, a, b = orc.parse_disp_entry_string(entry)
+    ref = orc.compute_loop_position_space(ev, sg, orc.LoopComputeParam(s, a, b), Uo, X)
+    expect = {"opt": [-1, 0, -1, 2, -1, -1, -1, 6], "opt_noreflect": [-1] * 8, "basic": [-1] * 8}
+    for mode in ("opt", "opt_noreflect", "basic"):
+        if mode == "opt_noreflect":
+            monkeypatch.setenv("MUGIQ_HIP_REFLECT", "0")
+        else:
+            monkeypatch.delenv("MUGIQ_HIP_REFLECT", raising=False)
+        prm = hip.MugiqLoopParam(gauge=U, calcType=hip.LOOP_CALC_TYPE_BASIC_KERNEL if mode == "basic" else hip.LOOP_CALC_TYPE_OPT_KERNEL)
+        loop = hip.Loop_Mugiq(prm.set_displace_entry_string(entry), f, sg)
+        loop.computeCoarseLoop()
+        assert [loop.derivedFrom(i) for i in range(8)] == expect[mode], mode     # "-x:1,3" is not covered by "+x:1,2"
+        assert rel_err(loop.dataPos_d.cpu().numpy(), ref) < 1e-12, mode
+        loop.close()

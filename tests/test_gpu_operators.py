@@ -526,3 +526,76 @@ def test_full_size_cfg3_local_shape_plus_minus_displacement_identity(hip):
             minus = pos[1 + 6 * axis + 3 + k, 0].sum().item()
             assert abs(plus - np.conj(minus)) < 1e-11 * max(abs(plus), 1e-3), (axis, k, plus, minus)
     loop.close()
+
+
+# ---- reflected displacement entries --------------------------------------------------------------------------------
+def _oracle_pm_slots(X, nev, name, kmax, seed):
+    rng = np.random.default_rng(seed)
+    ev = [orc.lex_to_eo(random_spinor_lex(rng, X), X) for _ in range(nev)]
+    U_lex = random_gauge_lex(rng, X)
+    Uo = orc.extended_gauge_from_global(U_lex, (0, 0, 0, 0), (1, 1, 1, 1), (0, 0, 0, 0))
+    cprm = orc.LoopComputeParam(["+" + name, "-" + name], [1, 1], [kmax, kmax])
+    V = int(np.prod(X))
+    pos = orc.compute_loop_position_space(ev, sigmas(nev), cprm, Uo, X).reshape(cprm.nLoop, 16 * V)
+    return pos[1:1 + kmax], pos[1 + kmax:1 + 2 * kmax]
+
+
+@pytest.mark.parametrize("prec", [8, 4])
+@pytest.mark.parametrize("X,name", [((4, 6, 4, 8), "x"), ((4, 6, 4, 8), "y"), ((6, 4, 2, 4), "z"), ((4, 4, 4, 2), "t")])
+def test_reflected_entry_equals_the_directly_computed_one(hip, prec, X, name):
+    """mugiq_hip_reflect_displaced_loop: the "-mu" slots from the "+mu" slots and back, lengths up to past the extent."""
+    kmax = 5
+    plus, minus = _oracle_pm_slots(X, 2, name, kmax, 88)
+    cdt = torch.complex128 if prec == 8 else torch.complex64
+    d = "xyzt".index(name)
+    V = int(np.prod(X))
+    for k in range(1, kmax + 1):
+        src = torch.from_numpy(plus[k - 1]).to(cdt).cuda()
+        dst = torch.zeros(16 * V, dtype=cdt, device="cuda")
+        hip.reflectDisplacedLoop(dst, src, X, d, hip.DispSignMinus, k)
+        assert rel_err(dst.cpu().numpy(), minus[k - 1]) < (1e-13 if prec == 8 else 1e-6), (name, k)
+        src = torch.from_numpy(minus[k - 1]).to(cdt).cuda()
+        hip.reflectDisplacedLoop(dst, src, X, d, hip.DispSignPlus, k)
+        assert rel_err(dst.cpu().numpy(), plus[k - 1]) < (1e-13 if prec == 8 else 1e-6), (name, k)
+    with pytest.raises(hip.MugiqHipError):
+        hip.reflectDisplacedLoop(dst, dst, X, d, hip.DispSignPlus, 1)                       # aliased
+    with pytest.raises(hip.MugiqHipError):
+        hip.reflectDisplacedLoop(dst, src, X, d, hip.DispSignPlus, 1, commDim=(1, 1, 1, 1))  # partitioned without ghost layers
+
+
+@pytest.mark.parametrize("dim", [0, 1, 2, 3])
+def test_reflected_entry_with_ghost_layers_matches_single_domain(hip, dim):
+    """Two domains along `dim` (one process): the k boundary layers of the source slot travel through
+    mugiq_hip_pack_loop_layers exactly as the driver sends them."""
+    G = [4, 4, 4, 4]
+    G[dim] = 8
+    G = tuple(G)
+    grid = [1, 1, 1, 1]
+    grid[dim] = 2
+    name = "xyzt"[dim]
+    kmax = 3
+    plus, minus = _oracle_pm_slots(G, 2, name, kmax, 99)
+    l = [G[d] // grid[d] for d in range(4)]
+    Vg, Vl = int(np.prod(G)), int(np.prod(l))
+    ranks = [tuple(1 if (d == dim and r == 1) else 0 for d in range(4)) for r in range(2)]
+    comm = tuple(1 if d == dim else 0 for d in range(4))
+
+    def local(slot, r):
+        out = np.empty(16 * Vl, dtype=np.complex128)
+        for ig in range(16):
+            gl = orc.eo_to_lex(slot[Vg * ig:Vg * (ig + 1)].reshape(2, Vg // 2), G)
+            out[Vl * ig:Vl * (ig + 1)] = orc.lex_to_eo(orc.local_block(gl, r, grid), l).reshape(-1)
+        return out
+
+    fcb = Vl // 2 // l[dim]
+    for k in range(1, kmax + 1):
+        for dst_sign, src_all, ref_all, high in ((hip.DispSignMinus, plus, minus, 1), (hip.DispSignPlus, minus, plus, 0)):
+            src = {r: torch.from_numpy(local(src_all[k - 1], r)).cuda() for r in ranks}
+            packed = {}
+            for r in ranks:
+                packed[r] = torch.zeros(32 * k * fcb, dtype=torch.complex128, device="cuda")
+                hip.packLoopLayers(packed[r], src[r], l, dim, high, k)
+            for i, r in enumerate(ranks):
+                dst = torch.zeros(16 * Vl, dtype=torch.complex128, device="cuda")
+                hip.reflectDisplacedLoop(dst, src[r], l, dim, dst_sign, k, comm, packed[ranks[1 - i]])   # 2 ranks: both neighbours are the other one
+                assert rel_err(dst.cpu().numpy(), local(ref_all[k - 1], r)) < 1e-13, (name, k, dst_sign, r)

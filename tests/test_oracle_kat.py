@@ -367,3 +367,40 @@ def test_prolongator_block_structure_and_adjoint_identity():
     assert buf[1 * (2 * nvec * vcbc) + (1 * nvec + 2) * vcbc + 3] == phi[1, 3, 1, 2]
     vb = orc.nullvec_to_native(V)
     assert vb[0 * (12 * nvec * vcb) + ((3 * 2 + 1) * nvec + 4) * vcb + 5] == V[0, 5, 2, 1, 4]
+
+
+# ---- (10) reflection: a minus-direction loop is the shifted conjugate of the plus-direction one -----------
+def gamma_dagger_sign():
+    """G(n)^dagger = eta_n G(n) for G(n) = g1^n0 g2^n1 g3^n2 g4^n3 (Hermitian, anticommuting factors):
+    eta = (-1)^(m(m-1)/2), m = number of factors."""
+    return np.array([(-1) ** ((bin(n).count("1") * (bin(n).count("1") - 1)) // 2) for n in range(16)])
+
+
+def test_gamma_dagger_signs():
+    for n in range(16):
+        G = orc.gamma_dense(n)
+        assert np.array_equal(G.conj().T, gamma_dagger_sign()[n] * G)
+
+
+def test_minus_entry_is_shifted_conjugate_of_plus_entry():
+    """W_{-k}(x) = W_{+k}(x - k mu)^dagger and [Gamma, W] = 0 give, slot by slot,
+        L^-_{k,G}(x) = eta_G * conj( L^+_{k,G}(x - k mu) ),
+    which lets the engine derive every "-mu" entry from the "+mu" entry of the same lengths (and vice versa)."""
+    X = (4, 6, 4, 8)
+    rng = np.random.default_rng(2024)
+    nev = 3
+    ev = [orc.lex_to_eo(random_spinor_lex(rng, X), X) for _ in range(nev)]
+    U = gauge_eo_single_domain(random_gauge_lex(rng, X), X)
+    V = int(np.prod(X))
+    eta = gamma_dagger_sign()
+    axis_of_dir = {0: 3, 1: 2, 2: 1, 3: 0}
+    for d, name in enumerate("xyzt"):
+        cprm = orc.LoopComputeParam(["+" + name, "-" + name], [1, 1], [3, 3])
+        pos = orc.compute_loop_position_space(ev, sigmas(nev), cprm, U, X).reshape(cprm.nLoop, 16, V)
+        for k in (1, 2, 3):
+            plus, minus = pos[1 + (k - 1)], pos[4 + (k - 1)]
+            for ig in range(16):
+                p_lex = orc.eo_to_lex(plus[ig].reshape(2, V // 2), X)
+                m_lex = orc.eo_to_lex(minus[ig].reshape(2, V // 2), X)
+                shifted = np.roll(p_lex, k, axis=axis_of_dir[d])          # value at x - k mu
+                assert rel_err(m_lex, eta[ig] * shifted.conj()) < 1e-13, (name, k, ig)
