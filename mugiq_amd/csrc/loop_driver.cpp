@@ -282,12 +282,14 @@ static int entry_reflected(MugiqHipLoop *lp, int id, int jd, void *slot0) {
   const char *src0 = static_cast<const char *>(lp->dataPos_d) + slotBytes * (size_t)lp->nLoopOffset[jd];
   const int faceCB = lp->volumeCB / lp->localL[dir];
   int st;
+  // a length that reaches past the nearest neighbour cannot be served by one halo: nothing is written, the caller
+  // computes the entry from the eigenvectors
+  if (part && lp->dispStop[id] > lp->localL[dir]) return -1;
   for (int k = lp->dispStart[id]; k <= lp->dispStop[id]; k++) {
     void *dst = static_cast<char *>(slot0) + slotBytes * (size_t)(k - lp->dispStart[id]);
     const void *src = src0 + slotBytes * (size_t)(k - lp->dispStart[jd]);
     void *grecv = nullptr;
     if (part) {
-      if (k > lp->localL[dir]) return -1;  // reaches past the nearest neighbour: let the caller compute the entry
       // dst "-": the source sites x - k mu below my block are the backward neighbour's top k layers, so every rank sends its
       // top layers forward; dst "+": bottom layers backward
       const int high = sign == MUGIQ_HIP_DISP_SIGN_MINUS ? 1 : 0;

@@ -119,7 +119,9 @@ def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8)):
     import mugiq_amd as hip
     # the last entry is longer than the local t extent on a t-partitioned grid: the OPT plan hands it to the
     # step-by-step sequence (one halo per step) instead of the multi-layer halo
-    disp = (["+t", "-t", "+z", "-z", "+x", "-y", "-t", "+y"], [1, 2, 1, 1, 1, 2, 5, 1], [3, 2, 2, 1, 1, 2, 5, 3])
+    # ... and "+t:5" after it has a computed opposite-sign source of the same length, which the OPT plan must NOT
+    # reflect on a t-partitioned grid (length > local extent) but may on the others
+    disp = (["+t", "-t", "+z", "-z", "+x", "-y", "-t", "+y", "+t"], [1, 2, 1, 1, 1, 2, 5, 1, 5], [3, 2, 2, 1, 1, 2, 5, 3, 5])
     moms = momenta_p2_le(2)
     FTSign = 1
     nev = 3
