@@ -87,6 +87,16 @@ struct MugiqHipLoop_s {
   };
   std::vector<PoolBuf> pool;
   std::vector<void *> scratch;  // pool buffers handed out for the current entry (returned by free_scratch)
+  // halos posted ahead of their entry (OPT plan): the eigenvector layers of every partitioned entry are packed and sent
+  // at the start of the compute, the entries of unpartitioned directions run while they travel
+  struct HaloPost {
+    void *gsend = nullptr, *grecv = nullptr;
+    hipEvent_t evPacked = nullptr, evHalo = nullptr;
+    bool posted = false;
+    std::vector<MugiqHipSpinorField> E;  // path-link fields built ahead (their small face exchanges go first)
+  };
+  std::vector<HaloPost> halo;   // per displacement entry
+  std::vector<void *> held;     // pool buffers held until the end of the compute
 
   size_t cplxBytes() const { return 2 * (size_t)precision; }      // eigenvector / link storage
   size_t loopBytes() const { return 2 * (size_t)loopPrecision; }  // loop buffers, phases, momentum projection
@@ -185,6 +195,72 @@ static int entry_basic(MugiqHipLoop *lp, int id, void *slot0) {
   return MUGIQ_HIP_SUCCESS;
 }
 
+// path-ordered link products W_k as E_k = D^k E_0, E_0(x)(s,c) = delta_sc, s < 3 (scratch fields; k = 0 .. stop)
+static int build_path_links(MugiqHipLoop *lp, int id, std::vector<MugiqHipSpinorField> &E) {
+  const int dir = lp->dispDir[id], sign = lp->dispSign[id], stop = lp->dispStop[id];
+  const bool part = lp->commDim[dir] != 0;
+  int st;
+  E.assign(stop + 1, MugiqHipSpinorField());
+  for (int k = 0; k <= stop; k++)
+    if ((st = make_scratch_field(lp, &E[k], 2, false))) return st;  // every site of E_k is written below
+  if ((st = fill_identity_links(&E[0], lp->stream))) return st;
+  void *send_d = nullptr, *recv_d = nullptr;
+  if (part) {
+    const size_t fb = (size_t)24 * (lp->volumeCB / lp->localL[dir]) * lp->cplxBytes();
+    if ((st = scratch_alloc(lp, &send_d, fb, false))) return st;
+    if ((st = scratch_alloc(lp, &recv_d, fb, false))) return st;
+  }
+  for (int k = 1; k <= stop; k++) {
+    if (part && (st = exchange_face(lp, &E[k - 1], dir, sign, send_d, recv_d))) return st;
+    if ((st = mugiq_hip_perform_covariant_displacement_vector(&E[k], &E[k - 1], &lp->gauge, dir, sign, lp->commDim, lp->stream)))
+      return st;
+  }
+  return MUGIQ_HIP_SUCCESS;
+}
+
+static int ensure_comm_stream(MugiqHipLoop *lp) {
+  if (!lp->commStream) {
+    MUGIQ_CHECK_HIP(hipStreamCreateWithFlags(&lp->commStream, hipStreamNonBlocking));
+    MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&lp->evPacked, hipEventDisableTiming));
+    MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&lp->evHalo, hipEventDisableTiming));
+  }
+  return MUGIQ_HIP_SUCCESS;
+}
+
+// Pack the `stop` boundary layers of ALL eigenvectors for entry `id` and hand them to the transport on the halo stream,
+// now; entry_fused picks the result up when its turn comes.  Skipped (entry_fused then exchanges block by block) when
+// the buffers would not fit `budget` bytes.
+static int post_halo(MugiqHipLoop *lp, int id, size_t *budget) {
+  const int dir = lp->dispDir[id], sign = lp->dispSign[id], stop = lp->dispStop[id];
+  const int faceCB = lp->volumeCB / lp->localL[dir];
+  const size_t bytes = (size_t)stop * 24 * faceCB * lp->cplxBytes() * (size_t)lp->nEv;
+  if (2 * bytes > *budget) return MUGIQ_HIP_SUCCESS;
+  int st;
+  if ((st = ensure_comm_stream(lp))) return st;
+  MugiqHipLoop::HaloPost &h = lp->halo[id];
+  if (!h.evPacked) {
+    MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&h.evPacked, hipEventDisableTiming));
+    MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&h.evHalo, hipEventDisableTiming));
+  }
+  // the link fields first: their (small) face exchanges must not queue up behind the eigenvector halos
+  if ((st = build_path_links(lp, id, h.E))) return st;
+  if ((st = scratch_alloc(lp, &h.gsend, bytes, false))) return st;
+  if ((st = scratch_alloc(lp, &h.grecv, bytes, false))) return st;
+  // all of these outlive the entries processed in between: move them from the per-entry list to the held list
+  for (void *q : lp->scratch) lp->held.push_back(q);
+  lp->scratch.clear();
+  *budget -= 2 * bytes;
+  const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
+  if ((st = mugiq_hip_pack_face_layers(h.gsend, lp->eVecs.data(), lp->nEv, dir, high, stop, lp->stream))) return st;
+  MUGIQ_CHECK_HIP(hipEventRecord(h.evPacked, lp->stream));
+  MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, h.evPacked, 0));
+  st = lp->comm.sendrecv(lp->comm.ctx, h.gsend, h.grecv, bytes, dir, high ? +1 : -1, lp->commStream);
+  if (st) return set_error(MUGIQ_HIP_ERROR_HIP, "halo sendrecv callback failed with status %d", st);
+  MUGIQ_CHECK_HIP(hipEventRecord(h.evHalo, lp->commStream));
+  h.posted = true;
+  return MUGIQ_HIP_SUCCESS;
+}
+
 // ---- the fused plan -------------------------------------------------------------------------------------------
 static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
   const int dir = lp->dispDir[id], sign = lp->dispSign[id];
@@ -194,45 +270,41 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
   // a displacement longer than the local extent of a partitioned dimension reaches past the nearest neighbour: the
   // multi-layer halo cannot serve it, the step-by-step sequence (one face per step) can
   if (part && stop > lp->localL[dir]) return entry_basic(lp, id, slot0);
-  // path-ordered link products W_k as E_k = D^k E_0, E_0(x)(s,c) = delta_sc, s < 3
-  std::vector<MugiqHipSpinorField> E(stop + 1);
-  for (int k = 0; k <= stop; k++)
-    if ((st = make_scratch_field(lp, &E[k], 2, false))) return st;  // every site of E_k is written below
-  if ((st = fill_identity_links(&E[0], lp->stream))) return st;
-  void *send_d = nullptr, *recv_d = nullptr;
-  const int faceCB = lp->volumeCB / lp->localL[dir];
-  if (part) {
-    const size_t fb = (size_t)24 * faceCB * lp->cplxBytes();
-    if ((st = scratch_alloc(lp, &send_d, fb, false))) return st;
-    if ((st = scratch_alloc(lp, &recv_d, fb, false))) return st;
-  }
-  for (int k = 1; k <= stop; k++) {
-    if (part && (st = exchange_face(lp, &E[k - 1], dir, sign, send_d, recv_d))) return st;
-    if ((st = mugiq_hip_perform_covariant_displacement_vector(&E[k], &E[k - 1], &lp->gauge, dir, sign, lp->commDim, lp->stream)))
-      return st;
-  }
+  std::vector<MugiqHipSpinorField> Elocal;
+  const bool ahead = part && lp->halo[id].posted;
+  if (!ahead && (st = build_path_links(lp, id, Elocal))) return st;
+  std::vector<MugiqHipSpinorField> &E = ahead ? lp->halo[id].E : Elocal;
   std::vector<const void *> links;
   std::vector<int> kv;
   for (int k = start; k <= stop; k++) {
     links.push_back(E[k].data);
     kv.push_back(k);
   }
+  if (part && lp->halo[id].posted) {
+    // the halo of all eigenvectors was posted at the start of the compute: interior tiles, then (once it has landed) the
+    // boundary tiles
+    MugiqHipLoop::HaloPost &h = lp->halo[id];
+    if ((st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, lp->eVecs.data(), lp->sigma.data(), lp->nEv,
+                                                                links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
+                                                                h.grecv, stop, MUGIQ_HIP_REGION_INTERIOR, lp->stream)))
+      return st;
+    MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->stream, h.evHalo, 0));
+    return mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, lp->eVecs.data(), lp->sigma.data(), lp->nEv,
+                                                             links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim, h.grecv,
+                                                             stop, MUGIQ_HIP_REGION_BOUNDARY, lp->stream);
+  }
   // eigenvector blocks: bounded by the ghost-layer buffers when the dimension is partitioned
   int nb = lp->nEv;
   void *gsend = nullptr, *grecv = nullptr;
   size_t perVec = 0;
   if (part) {
-    perVec = (size_t)stop * 24 * faceCB * lp->cplxBytes();
+    perVec = (size_t)stop * 24 * (lp->volumeCB / lp->localL[dir]) * lp->cplxBytes();
     const size_t budget = (size_t)4 << 30;  // 4 GiB per direction buffer
     nb = (int)std::max<size_t>(1, std::min<size_t>((size_t)lp->nEv, budget / perVec));
     if ((st = scratch_alloc(lp, &gsend, perVec * nb, false))) return st;
     if ((st = scratch_alloc(lp, &grecv, perVec * nb, false))) return st;
   }
-  if (part && !lp->commStream) {
-    MUGIQ_CHECK_HIP(hipStreamCreateWithFlags(&lp->commStream, hipStreamNonBlocking));
-    MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&lp->evPacked, hipEventDisableTiming));
-    MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&lp->evHalo, hipEventDisableTiming));
-  }
+  if (part && (st = ensure_comm_stream(lp))) return st;
   for (int n0 = 0; n0 < lp->nEv; n0 += nb) {
     const int nv = std::min(nb, lp->nEv - n0);
     if (!part) {
@@ -268,6 +340,8 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
 static int reflection_source(const MugiqHipLoop *lp, int id) {
   if (const char *e = getenv("MUGIQ_HIP_REFLECT"))
     if (atoi(e) == 0) return -1;
+  // a length that reaches past the nearest neighbour cannot be served by one halo of the source slot
+  if (lp->commDim[lp->dispDir[id]] && lp->dispStop[id] > lp->localL[lp->dispDir[id]]) return -1;
   for (int jd = 0; jd < id; jd++)
     if (lp->dispDir[jd] == lp->dispDir[id] && lp->dispSign[jd] != lp->dispSign[id] && lp->dispStart[jd] <= lp->dispStart[id] &&
         lp->dispStop[id] <= lp->dispStop[jd] && lp->derivedFrom[jd] < 0)
@@ -622,7 +696,41 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
     // prolongateEvec for every eigenvector, once (the reference repeats it per displacement entry, lib/loop_mugiq.cpp:482)
     if ((st = mugiq_hip_prolongate_batched(lp->eVecs.data(), lp->coarseVecs.data(), lp->nEv, &lp->transfer, lp->stream))) return st;
   }
-  for (int id = -1; id < lp->nDispEntries; id++) {  // lib/loop_mugiq.cpp:455
+  // ---- plan (OPT): which entries are reflected from which, and in what order things run.  The slots are independent,
+  // so the order of lib/loop_mugiq.cpp:455 is kept for BASIC only; OPT posts the eigenvector halos of all partitioned
+  // entries first, runs the ultra-local loop and the entries of unpartitioned directions while they travel, then the
+  // partitioned entries (interior tiles before the halo is waited for), and the reflected entries last.
+  std::vector<int> order;
+  order.push_back(-1);
+  if (basic) {
+    for (int id = 0; id < lp->nDispEntries; id++) {
+      lp->derivedFrom[id] = -1;
+      order.push_back(id);
+    }
+  } else {
+    lp->halo.resize(lp->nDispEntries);
+    for (int id = 0; id < lp->nDispEntries; id++) {
+      lp->derivedFrom[id] = -1;  // entries after `id` are still -1 here: reflection_source only looks at jd < id
+      lp->derivedFrom[id] = reflection_source(lp, id);
+      lp->halo[id].posted = false;
+    }
+    size_t freeB = 0, totalB = 0;
+    MUGIQ_CHECK_HIP(hipMemGetInfo(&freeB, &totalB));
+    size_t budget = freeB / 2;  // ghost-layer buffers posted ahead may take half of what is free now
+    if (const char *e = getenv("MUGIQ_HIP_HALO_AHEAD"))
+      if (atoi(e) == 0) budget = 0;
+    for (int id = 0; id < lp->nDispEntries; id++) {
+      const int dir = lp->dispDir[id];
+      if (lp->derivedFrom[id] < 0 && lp->commDim[dir] && lp->dispStop[id] <= lp->localL[dir])
+        if ((st = post_halo(lp, id, &budget))) return st;
+    }
+    for (int pass = 0; pass < 3; pass++)
+      for (int id = 0; id < lp->nDispEntries; id++) {
+        const bool derived = lp->derivedFrom[id] >= 0, part = lp->commDim[lp->dispDir[id]] != 0;
+        if ((pass == 0 && !derived && !part) || (pass == 1 && !derived && part) || (pass == 2 && derived)) order.push_back(id);
+      }
+  }
+  for (int id : order) {
     long long bufOffset;
     size_t bufByteSize;
     if (id != -1) {  // :465-474
@@ -648,26 +756,25 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
                                                               lp->sigma.data(), lp->nEv, lp->stream);
       }
     } else {
-      lp->derivedFrom[id] = -1;
-      int done = 0;
-      if (!basic) {  // the OPT plan derives a "-mu" entry from the "+mu" entry of the same lengths (or vice versa)
-        const int jd = reflection_source(lp, id);
-        if (jd >= 0) {
-          st = entry_reflected(lp, id, jd, slot0);
-          if (st == -1) st = MUGIQ_HIP_SUCCESS;  // not derivable after all (length beyond the neighbour): compute it
-          else {
-            done = 1;
-            lp->derivedFrom[id] = jd;
-          }
-        }
-      }
-      if (!done) st = basic ? entry_basic(lp, id, slot0) : entry_fused(lp, id, slot0);
+      if (basic) st = entry_basic(lp, id, slot0);
+      else if (lp->derivedFrom[id] >= 0) st = entry_reflected(lp, id, lp->derivedFrom[id], slot0);
+      else st = entry_fused(lp, id, slot0);
       hipError_t e = hipStreamSynchronize(lp->stream);
       free_scratch(lp);
       if (!st && e != hipSuccess) st = set_error(MUGIQ_HIP_ERROR_HIP, "computeCoarseLoop: %s", hipGetErrorString(e));
     }
-    if (st) return st;
+    if (st) break;
   }
+  // hand the buffers of the posted halos back (their transfers were waited for by the entries that used them; after an
+  // error drain the halo stream first)
+  if (!lp->held.empty()) {
+    if (st && lp->commStream) (void)hipStreamSynchronize(lp->commStream);
+    for (void *p : lp->held)
+      for (auto &b : lp->pool)
+        if (b.ptr == p) b.inUse = false;
+    lp->held.clear();
+  }
+  if (st) return st;
   lp->dataPosCopied = false;
   if (lp->doMomProj && (st = momentum_projection(lp))) return st;  // :517-520
   MUGIQ_CHECK_HIP(hipStreamSynchronize(lp->stream));
@@ -791,6 +898,10 @@ int mugiq_hip_loop_destroy(MugiqHipLoop *lp) {  // freeDataMemory, lib/loop_mugi
   free(lp->dataMom);
   free(lp->dataPos);
   if (lp->fineStore) (void)hipFree(lp->fineStore);
+  for (auto &h : lp->halo) {
+    if (h.evPacked) (void)hipEventDestroy(h.evPacked);
+    if (h.evHalo) (void)hipEventDestroy(h.evHalo);
+  }
   if (lp->evPacked) (void)hipEventDestroy(lp->evPacked);
   if (lp->evHalo) (void)hipEventDestroy(lp->evHalo);
   if (lp->commStream) (void)hipStreamDestroy(lp->commStream);
