@@ -316,6 +316,13 @@ typedef struct MugiqHipComm_s {
   int (*gather_time)(void *ctx, const void *send_h, void *recv_h, size_t n_real_per_rank, int precision);
   /* MPI_Bcast from world rank 0 (lib/loop_mugiq.cpp:424) */
   int (*bcast)(void *ctx, void *buf_h, size_t n_real, int precision);
+  /* Optional (both NULL or both set).  The OPT plan posts the eigenvector halos of ALL partitioned entries at the start
+   * of a compute: between group_begin and group_end it issues one sendrecv per such entry, all on the same stream and
+   * to different neighbours.  A transport that can run them concurrently (different xGMI links: ncclGroupStart/End;
+   * MPI_Isend/Irecv + Waitall) may defer them until group_end(ctx, stream); one without these members runs every
+   * sendrecv as it comes. */
+  int (*group_begin)(void *ctx);
+  int (*group_end)(void *ctx, void *stream);
 } MugiqHipComm;
 
 /* MugiqLoopParam (include/mugiq.h:28-47) with C arrays instead of std::vector/std::string.

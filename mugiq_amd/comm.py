@@ -56,6 +56,7 @@ class GridComm:
         self.time_group = dist.new_group(self.time_ranks)
         self.is_time_process = self.coord[:3] == (0, 0, 0)
         self._cb = None
+        self._group = None            # deferred (send, recv, staged recv target, dst, src) while a group is open
 
     # ---- topology (QUDA's comm_rank_from_coords: x slowest, t fastest) --------------------------------------
     def coords_of(self, rank):
@@ -86,6 +87,9 @@ class GridComm:
         stage = self.backend == "gloo" and send.is_cuda
         s = send.cpu() if stage else send
         r = torch.empty_like(recv, device="cpu") if stage else recv
+        if self._group is not None and dst != self.rank:
+            self._group.append((s, r, recv if stage else None, dst, src))     # issued together at group_end
+            return
         if dst == self.rank:                      # grid of 1 in this dim (not called by the driver) -> periodic copy
             r.copy_(s)
         else:
@@ -94,6 +98,24 @@ class GridComm:
                 w.wait()
         if stage:
             recv.copy_(r)
+
+    def group_begin(self):
+        """Defer the sendrecv calls that follow: the halos of different axes go to different neighbours and can share one
+        batch (ncclGroupStart/End under torch's batch_isend_irecv), i.e. use their xGMI links at the same time."""
+        self._group = []
+
+    def group_end(self):
+        pending, self._group = self._group, None
+        if not pending:
+            return
+        ops = []
+        for s, r, _, dst, src in pending:
+            ops += [dist.P2POp(dist.isend, s, dst), dist.P2POp(dist.irecv, r, src)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for s, r, target, _, _ in pending:
+            if target is not None:
+                target.copy_(r)
 
     # ---- FT reduction (host-side payloads, tiny) -----------------------------------------------------------------
     def _wire(self, t):
@@ -141,26 +163,30 @@ class GridComm:
                     return 1
             return wrapped
 
-        def c_sendrecv(ctx, send_d, recv_d, nbytes, dim, direction, stream):
+        import contextlib
+
+        @contextlib.contextmanager
+        def _stream_ctx(stream):
             # `stream` is the stream the driver ordered the pack kernel on (its compute stream, or its halo stream
             # when the transfer overlaps the interior sites).  torch's collectives order against torch's CURRENT
             # stream, so make `stream` current for the duration of the exchange.
-            s = device_bytes(send_d, nbytes, self.device)
-            r = device_bytes(recv_d, nbytes, self.device)
             cur = torch.cuda.current_stream(self.device)
             ptr = int(stream) if stream else 0
-            ctxmgr = torch.cuda.stream(torch.cuda.ExternalStream(ptr, device=self.device)) if ptr != cur.cuda_stream else None
-            if ctxmgr is not None:
-                ctxmgr.__enter__()
-            try:
+            if ptr != cur.cuda_stream:
+                with torch.cuda.stream(torch.cuda.ExternalStream(ptr, device=self.device)):
+                    yield
+            else:
+                yield
+
+        def c_sendrecv(ctx, send_d, recv_d, nbytes, dim, direction, stream):
+            s = device_bytes(send_d, nbytes, self.device)
+            r = device_bytes(recv_d, nbytes, self.device)
+            with _stream_ctx(stream):
                 if self.backend == "gloo":
                     torch.cuda.current_stream(self.device).synchronize()      # staging through the host
                 self.sendrecv(s, r, dim, direction)
-                if self.backend == "gloo":
+                if self.backend == "gloo" and self._group is None:
                     torch.cuda.current_stream(self.device).synchronize()
-            finally:
-                if ctxmgr is not None:
-                    ctxmgr.__exit__(None, None, None)
 
         def c_reduce(ctx, send_h, recv_h, n, prec):
             s = torch.from_numpy(host_array(send_h, n, prec))
@@ -175,18 +201,34 @@ class GridComm:
         def c_bcast(ctx, buf_h, n, prec):
             self.bcast(torch.from_numpy(host_array(buf_h, n, prec)))
 
+        GBEGIN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
+        GEND = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+
+        def c_group_begin(ctx):
+            self.group_begin()
+
+        def c_group_end(ctx, stream):
+            with _stream_ctx(stream):
+                if self.backend == "gloo":
+                    torch.cuda.current_stream(self.device).synchronize()      # the pack kernels feeding the staged copies
+                self.group_end()
+                if self.backend == "gloo":
+                    torch.cuda.current_stream(self.device).synchronize()
+
         class CComm(ctypes.Structure):
             _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("size", ctypes.c_int),
                         ("grid", ctypes.c_int * 4), ("coord", ctypes.c_int * 4),
-                        ("sendrecv", SENDRECV), ("reduce_space", REDUCE), ("gather_time", REDUCE), ("bcast", BCAST)]
+                        ("sendrecv", SENDRECV), ("reduce_space", REDUCE), ("gather_time", REDUCE), ("bcast", BCAST),
+                        ("group_begin", GBEGIN), ("group_end", GEND)]
 
-        fns = (SENDRECV(guard(c_sendrecv)), REDUCE(guard(c_reduce)), REDUCE(guard(c_gather)), BCAST(guard(c_bcast)))
+        fns = (SENDRECV(guard(c_sendrecv)), REDUCE(guard(c_reduce)), REDUCE(guard(c_gather)), BCAST(guard(c_bcast)),
+               GBEGIN(guard(c_group_begin)), GEND(guard(c_group_end)))
         c = CComm()
         c.ctx = None
         c.rank, c.size = self.rank, self.size
         for d in range(4):
             c.grid[d] = self.grid[d]
             c.coord[d] = self.coord[d]
-        c.sendrecv, c.reduce_space, c.gather_time, c.bcast = fns
+        c.sendrecv, c.reduce_space, c.gather_time, c.bcast, c.group_begin, c.group_end = fns
         self._cb = (c, fns)          # keep the callbacks alive
         return c

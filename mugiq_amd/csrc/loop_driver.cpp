@@ -227,22 +227,20 @@ static int ensure_comm_stream(MugiqHipLoop *lp) {
   return MUGIQ_HIP_SUCCESS;
 }
 
-// Pack the `stop` boundary layers of ALL eigenvectors for entry `id` and hand them to the transport on the halo stream,
-// now; entry_fused picks the result up when its turn comes.  Skipped (entry_fused then exchanges block by block) when
-// the buffers would not fit `budget` bytes.
-static int post_halo(MugiqHipLoop *lp, int id, size_t *budget) {
+// Halo of entry `id` posted ahead, step 1: link fields (their small face exchanges happen here, at once), ghost buffers
+// for ALL eigenvectors, pack kernel.  Skipped (entry_fused then exchanges block by block in its own turn) when the
+// buffers would not fit `budget` bytes.
+static int prepare_halo(MugiqHipLoop *lp, int id, size_t *budget) {
   const int dir = lp->dispDir[id], sign = lp->dispSign[id], stop = lp->dispStop[id];
   const int faceCB = lp->volumeCB / lp->localL[dir];
   const size_t bytes = (size_t)stop * 24 * faceCB * lp->cplxBytes() * (size_t)lp->nEv;
   if (2 * bytes > *budget) return MUGIQ_HIP_SUCCESS;
   int st;
-  if ((st = ensure_comm_stream(lp))) return st;
   MugiqHipLoop::HaloPost &h = lp->halo[id];
   if (!h.evPacked) {
     MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&h.evPacked, hipEventDisableTiming));
     MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&h.evHalo, hipEventDisableTiming));
   }
-  // the link fields first: their (small) face exchanges must not queue up behind the eigenvector halos
   if ((st = build_path_links(lp, id, h.E))) return st;
   if ((st = scratch_alloc(lp, &h.gsend, bytes, false))) return st;
   if ((st = scratch_alloc(lp, &h.grecv, bytes, false))) return st;
@@ -253,11 +251,19 @@ static int post_halo(MugiqHipLoop *lp, int id, size_t *budget) {
   const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
   if ((st = mugiq_hip_pack_face_layers(h.gsend, lp->eVecs.data(), lp->nEv, dir, high, stop, lp->stream))) return st;
   MUGIQ_CHECK_HIP(hipEventRecord(h.evPacked, lp->stream));
-  MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, h.evPacked, 0));
-  st = lp->comm.sendrecv(lp->comm.ctx, h.gsend, h.grecv, bytes, dir, high ? +1 : -1, lp->commStream);
-  if (st) return set_error(MUGIQ_HIP_ERROR_HIP, "halo sendrecv callback failed with status %d", st);
-  MUGIQ_CHECK_HIP(hipEventRecord(h.evHalo, lp->commStream));
   h.posted = true;
+  return MUGIQ_HIP_SUCCESS;
+}
+
+// step 2: hand the packed layers to the transport on the halo stream (possibly inside a transfer group)
+static int send_halo(MugiqHipLoop *lp, int id) {
+  const int dir = lp->dispDir[id], sign = lp->dispSign[id], stop = lp->dispStop[id];
+  const size_t bytes = (size_t)stop * 24 * (lp->volumeCB / lp->localL[dir]) * lp->cplxBytes() * (size_t)lp->nEv;
+  const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
+  MugiqHipLoop::HaloPost &h = lp->halo[id];
+  MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, h.evPacked, 0));
+  const int st = lp->comm.sendrecv(lp->comm.ctx, h.gsend, h.grecv, bytes, dir, high ? +1 : -1, lp->commStream);
+  if (st) return set_error(MUGIQ_HIP_ERROR_HIP, "halo sendrecv callback failed with status %d", st);
   return MUGIQ_HIP_SUCCESS;
 }
 
@@ -719,10 +725,27 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
     size_t budget = freeB / 2;  // ghost-layer buffers posted ahead may take half of what is free now
     if (const char *e = getenv("MUGIQ_HIP_HALO_AHEAD"))
       if (atoi(e) == 0) budget = 0;
-    for (int id = 0; id < lp->nDispEntries; id++) {
-      const int dir = lp->dispDir[id];
-      if (lp->derivedFrom[id] < 0 && lp->commDim[dir] && lp->dispStop[id] <= lp->localL[dir])
-        if ((st = post_halo(lp, id, &budget))) return st;
+    const bool grouped = lp->haveComm && lp->comm.group_begin && lp->comm.group_end;
+    bool any = false;
+    for (int id = 0; id < lp->nDispEntries && budget > 0; id++)
+      any = any || (lp->derivedFrom[id] < 0 && lp->commDim[lp->dispDir[id]] && lp->dispStop[id] <= lp->localL[lp->dispDir[id]]);
+    if (any) {
+      if ((st = ensure_comm_stream(lp))) return st;
+      for (int id = 0; id < lp->nDispEntries; id++) {
+        const int dir = lp->dispDir[id];
+        if (lp->derivedFrom[id] < 0 && lp->commDim[dir] && lp->dispStop[id] <= lp->localL[dir])
+          if ((st = prepare_halo(lp, id, &budget))) return st;
+      }
+      if (grouped && (st = lp->comm.group_begin(lp->comm.ctx))) return set_error(MUGIQ_HIP_ERROR_HIP, "group_begin callback failed with status %d", st);
+      for (int id = 0; id < lp->nDispEntries && !st; id++)
+        if (lp->halo[id].posted) st = send_halo(lp, id);
+      if (grouped) {
+        const int st2 = lp->comm.group_end(lp->comm.ctx, lp->commStream);
+        if (!st && st2) st = set_error(MUGIQ_HIP_ERROR_HIP, "group_end callback failed with status %d", st2);
+      }
+      if (st) return st;
+      for (int id = 0; id < lp->nDispEntries; id++)
+        if (lp->halo[id].posted) MUGIQ_CHECK_HIP(hipEventRecord(lp->halo[id].evHalo, lp->commStream));
     }
     for (int pass = 0; pass < 3; pass++)
       for (int id = 0; id < lp->nDispEntries; id++) {

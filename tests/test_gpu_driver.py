@@ -145,6 +145,12 @@ def test_two_rank_driver_interior_boundary_tiles(grid, G, prec, order):
     mp.spawn(mp_workers.gpu_worker, args=(2, free_port(), grid, prec, order, 2, G), nprocs=2, join=True)
 
 
+def test_four_rank_driver_z_and_t_partitioned_on_one_gpu():
+    """configs[2]'s kind of grid (z and t partitioned): the halos of the two axes are posted together at the start of
+    the compute and travel in one transfer group (GridComm.group_begin / group_end)."""
+    mp.spawn(mp_workers.gpu_worker, args=(4, free_port(), (1, 1, 2, 2), 8, 2, 1), nprocs=4, join=True)
+
+
 def test_driver_writes_reference_hdf5_tree(hip, tmp_path):
     """computeLoop -> writeLoopsHDF5 (lib/interface_mugiq.cpp:158-172): file contents == dataMom_bcast."""
     import h5read
