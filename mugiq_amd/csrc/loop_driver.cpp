@@ -720,9 +720,12 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
       lp->derivedFrom[id] = reflection_source(lp, id);
       lp->halo[id].posted = false;
     }
+    // ghost-layer buffers posted ahead may take a quarter of the device memory.  The rule must not depend on anything
+    // that can differ between ranks (such as the memory free right now): every rank has to take the same decision, or
+    // the transfers would not pair up
     size_t freeB = 0, totalB = 0;
     MUGIQ_CHECK_HIP(hipMemGetInfo(&freeB, &totalB));
-    size_t budget = freeB / 2;  // ghost-layer buffers posted ahead may take half of what is free now
+    size_t budget = totalB / 4;
     if (const char *e = getenv("MUGIQ_HIP_HALO_AHEAD"))
       if (atoi(e) == 0) budget = 0;
     const bool grouped = lp->haveComm && lp->comm.group_begin && lp->comm.group_end;
