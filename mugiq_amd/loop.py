@@ -114,6 +114,7 @@ class Loop_Mugiq:
         """`transfer` given: eVecs are CoarseField eigenvectors (eigsolve->computeCoarse) prolonged with it."""
         lib = _lib.load()
         self._keep = []
+        self._params, self._transfer = loopParams, transfer
         p = _CLoopParam()
         n_mom = int(loopParams.Nmom) if loopParams.Nmom else len(loopParams.momMatrix)
         mom = np.ascontiguousarray(np.asarray(loopParams.momMatrix, dtype=np.int32).reshape(-1)) if n_mom else np.zeros(0, np.int32)
@@ -172,6 +173,43 @@ class Loop_Mugiq:
         out = (ctypes.c_int * 6)()
         _lib.check(_lib.load().mugiq_hip_loop_get_entry(self._handle, idx, out))
         return tuple(out)
+
+    def printLoopComputeParams(self, out=print):
+        """Loop_Mugiq::printLoopComputeParams (lib/loop_mugiq.cpp:233-273): the same report, line by line; the lines that
+        named CUDA libraries name what runs here."""
+        p, coarse = self._params, self._transfer is not None
+        out("******************************************")
+        out("    Parameters of the Loop Computation")
+        out("Precision is %s" % ("single" if self.precision == 4 else "double"))
+        if self.loopPrecision != self.precision:
+            out("Loop buffers and Fourier transform in double precision (mixed mode)")
+        out("Will%s use Multigrid" % ("" if coarse else " NOT"))
+        out("Working with %s operators/fields" % ("coarse" if coarse else "fine"))
+        out("Will%s perform Momentum Projection (Fourier Transform)" % ("" if p.doMomProj else " NOT"))
+        if p.doMomProj:
+            out("Momentum Projection will be performed on GPU using the split-K HIP kernel")
+            out("Number of momenta: %d" % self.Nmom)
+            out("Fourier transform Exp. Sign: %d" % int(p.FTSign))
+        nonlocal_ = self.nDispEntries > 0
+        out("Will%s perform loop on non-local currents" % ("" if nonlocal_ else " NOT"))
+        if nonlocal_:
+            out("Will perform ultra-local loop, plus the following %d displacement entries:" % self.nDispEntries)
+            for i in range(self.nDispEntries):
+                d, sgn, a, b, n, off = self.entry(i)
+                name = ("+" if sgn == 1 else "-") + "xyzt"[d]
+                if a == b:
+                    out("  %d: %s with length %d, #loops = %d, loop-offset = %d" % (i, name, a, n, off))
+                else:
+                    out("  %d: %s with lengths from %d to %d, #loops = %d, loop-offset = %d" % (i, name, a, b, n, off))
+        out("Total number of Loop Traces to perform: %d" % self.nLoop)
+        out("Local  lattice size (x,y,z,t): %d %d %d %d " % self.localL)
+        out("Global lattice size (x,y,z,t): %d %d %d %d " % self.totalL)
+        out("Global time extent: %d" % self.totT)
+        out("Local  time extent: %d" % self.locT)
+        out("Local  volume: %d" % self.locV4)
+        out("Local  3d volume: %d" % self.locV3)
+        out("Global 3d volume: %d" % self.totV3)
+        out("******************************************")
 
     def derivedFrom(self, idx):
         """After computeCoarseLoop: the entry that entry `idx` was reflected from (opposite sign, same direction and

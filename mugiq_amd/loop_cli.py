@@ -173,6 +173,8 @@ def main(argv=None):
         prm.loopPrecision = 8
 
     loop = Loop_Mugiq(prm, fields, sigma, comm)
+    if rank == 0:
+        loop.printLoopComputeParams(lambda line: print(line, file=sys.stderr))
     loop.computeCoarseLoop()
     if prm.doMomProj and prm.writeMomSpaceHDF5:
         loop.writeLoopsHDF5()

@@ -46,6 +46,13 @@ def test_driver_single_process_vs_oracle(hip, prec, order, calc):
         assert loop.entry(i) == (d, sgn, cprm.dispStart[i], cprm.dispStop[i], cprm.nLoopPerEntry[i], cprm.nLoopOffset[i])
     V = int(np.prod(X))
     assert loop.nElemPosLoc == 16 * V * cprm.nLoop and loop.nElemMomTot == 16 * len(moms) * X[3] * cprm.nLoop
+    lines = []
+    loop.printLoopComputeParams(lines.append)                       # lib/loop_mugiq.cpp:233-273
+    assert "Precision is %s" % ("double" if prec == 8 else "single") in lines and "Will NOT use Multigrid" in lines
+    assert "  0: +z with lengths from 1 to 2, #loops = 2, loop-offset = 1" in lines
+    assert "  1: -x with length 2, #loops = 1, loop-offset = 3" in lines
+    assert "  2: +t with lengths from 1 to 3, #loops = 3, loop-offset = 4" in lines      # start > stop was swapped
+    assert "Total number of Loop Traces to perform: %d" % cprm.nLoop in lines and "Local  3d volume: %d" % (X[0] * X[1] * X[2]) in lines
     loop.computeCoarseLoop()
     ref_pos = orc.compute_loop_position_space(ev, sg, cprm, Uo, X)
     tol = 1e-12 if prec == 8 else 1e-5
