@@ -45,6 +45,7 @@ def parse():
                     help="8 with --precision 4 = mixed precision (fp32 storage, fp64 accumulation; configs[3])")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the displaced-loop job reported under also_measured (N=1 only)")
     return ap.parse_args()
 
 
@@ -102,6 +103,41 @@ def cpu_baseline(fields, sigmas, X, prec, order, budget_s):
     return {"value": sites_per_s, "unit": "sites/s", "cores": threads, "kind": "port",
             "sample": "%d sites x %d eigenvectors (first %d checkerboard sites of each parity of the bench fields), "
                       "%d passes in %.1f s, oracle/mugiq_oracle.c with OpenMP" % (2 * S, nev, S, passes, el)}, loop, S
+
+
+def displaced_extra(hip, device, nev=100):
+    """Not the headline metric: the displaced-loop job of BASELINE.json configs[2] on its per-GPU lattice (48.48.24.24,
+    8 entries x lengths 1..3 = 25 loop slots) with N_ev reduced to 100, through the driver's OPT plan, for the record."""
+    X = (48, 48, 24, 24)
+    V = int(np.prod(X))
+    vcb = V // 2
+    _, fields = make_evecs(hip, X, nev, 8, 2, device, seed=4242)
+    g = hip.GaugeField(X, (0, 0, 0, 0), 8)
+    gen = torch.Generator(device=device).manual_seed(20240501)
+    m = torch.complex(torch.randn(4 * 2 * vcb, 3, 3, dtype=torch.float64, device=device, generator=gen),
+                      torch.randn(4 * 2 * vcb, 3, 3, dtype=torch.float64, device=device, generator=gen))
+    r0 = m[:, 0] / torch.linalg.vector_norm(m[:, 0], dim=-1, keepdim=True)
+    r1 = m[:, 1] - (r0.conj() * m[:, 1]).sum(-1, keepdim=True) * r0
+    r1 = r1 / torch.linalg.vector_norm(r1, dim=-1, keepdim=True)
+    r2 = torch.linalg.cross(r0.conj(), r1.conj())                       # det = 1
+    q = torch.stack([r0, r1, r2], dim=1).reshape(4, 2, vcb, 9).permute(1, 0, 3, 2).contiguous()   # [parity][dir][row*3+col][x_cb]
+    g.data.copy_(q.reshape(-1))
+    del m, r0, r1, r2, q
+    entries = "+x:1,3;-x:1,3;+y:1,3;-y:1,3;+z:1,3;-z:1,3;+t:1,3;-t:1,3"
+    prm = hip.MugiqLoopParam(gauge=g, calcType=hip.LOOP_CALC_TYPE_OPT_KERNEL).set_displace_entry_string(entries)
+    loop = hip.Loop_Mugiq(prm, fields, 0.01 + 0.002 * np.arange(nev))
+    times = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop.computeCoarseLoop()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    derived = sum(1 for i in range(loop.nDispEntries) if loop.derivedFrom(i) >= 0)
+    out = {"workload": "48x48x24x24 fp64 N_ev=%d, displacement entries %s (%d loop slots), driver OPT plan" % (nev, entries, loop.nLoop),
+           "seconds": min(times[1:]), "sites_per_s_all_slots": V / min(times[1:]), "entries_reflected": derived}
+    loop.close()
+    return out
 
 
 def main():
@@ -202,6 +238,10 @@ def main():
         err = float(np.max(np.abs(g - cpu_loop)) / np.max(np.abs(cpu_loop)))
         base["max_rel_err_gpu_vs_cpu_on_sample"] = err
         out["cpu_baseline"] = base
+    if rank == 0 and world == 1 and not a.no_extra:
+        del fields, big, loop
+        torch.cuda.empty_cache()
+        out["also_measured"] = {"displaced_loops": displaced_extra(hip, device)}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
