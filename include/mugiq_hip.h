@@ -245,6 +245,18 @@ int mugiq_hip_momentum_projection(void *dataMom_d, const void *dataPosMP_d, cons
                                   int locT, int nData, long long locV3, int Nmom, int precision,
                                   void *workspace_d, size_t workspace_bytes, void *stream);
 
+/* The same projection without the dense phase matrix (new).  exp(i s 2 pi p.x/L) factorises over x, y, z, so the sum over
+ * the local spatial volume is taken one direction at a time, for the distinct p_x, then the distinct (p_x, p_y), then
+ * the momenta: A is read once and the work drops from K*Nmom to about K*(number of distinct p_x) complex multiply-adds
+ * per row.  Takes what createPhaseMatrixGPU takes (momMatrix_h [Nmom][3], FTSign, localL, totalL, commCoord) instead of
+ * its output; the phases are rounded like the reference's, one direction at a time.  Same result to rounding. */
+size_t mugiq_hip_momentum_projection_separable_workspace(const int *momMatrix_h, int Nmom, const int localL[4], int locT,
+                                                          int nData, int precision);
+int mugiq_hip_momentum_projection_separable(void *dataMom_d, const void *dataPosMP_d, const int *momMatrix_h, int Nmom,
+                                            int FTSign, const int localL[4], const int totalL[4], const int commCoord[4],
+                                            int locT, int nData, int precision, void *workspace_d, size_t workspace_bytes,
+                                            void *stream);
+
 /* ==== f2: MG coarse path -- Loop_Mugiq::prolongateEvec (lib/loop_mugiq.cpp:277-319) = QUDA Transfer::P ============== */
 
 /* A coarse-grid colour-spinor in QUDA's FLOAT2 order (what Eigsolve_Mugiq hands over when computeCoarse is set,

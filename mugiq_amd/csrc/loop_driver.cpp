@@ -407,9 +407,21 @@ static int momentum_projection(MugiqHipLoop *lp) {
   if ((st = mugiq_hip_convert_idx_order_map_gamma(lp->dataPosMP_d, lp->dataPos_d, lp->nData, lp->nLoop, 2, lp->volumeCB,
                                                   lp->localL, lp->loopPrecision, lp->stream)))  // :343-344
     return st;
-  if ((st = mugiq_hip_momentum_projection(lp->dataMom_d, lp->dataPosMP_d, lp->phaseMatrix_d, lp->locT, lp->nData, lp->locV3,
-                                          lp->Nmom, lp->loopPrecision, nullptr, 0, lp->stream)))  // :363-378
-    return st;
+  if (lp->calcType == MUGIQ_HIP_LOOP_CALC_TYPE_BASIC_KERNEL) {
+    // the reference's formulation: one dense product with the phase matrix of createPhaseMatrixGPU   :363-378
+    if ((st = mugiq_hip_momentum_projection(lp->dataMom_d, lp->dataPosMP_d, lp->phaseMatrix_d, lp->locT, lp->nData, lp->locV3,
+                                            lp->Nmom, lp->loopPrecision, nullptr, 0, lp->stream)))
+      return st;
+  } else {
+    // OPT: the same sums taken one spatial direction at a time (csrc/momproj.hip)
+    int coord[4] = {0, 0, 0, 0};
+    if (lp->haveComm)
+      for (int d = 0; d < 4; d++) coord[d] = lp->comm.coord[d];
+    if ((st = mugiq_hip_momentum_projection_separable(lp->dataMom_d, lp->dataPosMP_d, lp->momMatrix.data(), lp->Nmom, lp->FTSign,
+                                                      lp->localL, lp->totalL, coord, lp->locT, lp->nData, lp->loopPrecision, nullptr,
+                                                      0, lp->stream)))
+      return st;
+  }
   const size_t locBytes = (size_t)lp->nElemMomLoc * lp->loopBytes();
   MUGIQ_CHECK_HIP(hipMemcpyAsync(lp->dataMom_h, lp->dataMom_d, locBytes, hipMemcpyDeviceToHost, lp->stream));  // :386
   MUGIQ_CHECK_HIP(hipStreamSynchronize(lp->stream));

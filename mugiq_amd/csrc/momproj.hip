@@ -8,7 +8,11 @@
 // combined in a fixed order by a second kernel (deterministic, no atomics).
 #include "internal.h"
 
+#include <algorithm>
+#include <cmath>
+#include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace mugiq {
 
@@ -154,6 +158,222 @@ static int own_workspace(void **ptr, size_t bytes) {
   return MUGIQ_HIP_SUCCESS;
 }
 
+
+// ---- separable form of the same projection -------------------------------------------------------------------------
+// The phase of lib/mugiq_util_kernels.cu:3-35 factorises, exp(i s 2 pi p.x/L) = f_x(p_x, x) f_y(p_y, y) f_z(p_z, z), so the
+// M x K x N product can be taken one spatial direction at a time:
+//   step x:  T1[z,y,ipx,m]  = sum_x  A[z,y,x,m]        f_x(px,x)      for the DISTINCT p_x of the momentum list
+//   step y:  T2[z,ipxy,m]   = sum_y  T1[z,y,ipx,m]     f_y(py,y)      for the distinct (p_x,p_y) pairs
+//   step z:  C[m,n]         = sum_z  T2[z,ipxy(n),m]   f_z(pz,z)      for the momenta themselves
+// 123 momenta with p^2 <= 9 have 7 distinct p_x: step x costs 7 complex multiply-adds per element of A instead of 123
+// and is bound by reading A once (the bound SURVEY.md section 8 names for this row); the later steps work on arrays
+// Lx and Lx*Ly times smaller.  Same sums in a different order: agrees with the dense product to rounding.
+constexpr int kDftJT = 8;  // outputs per lane
+
+template <typename F> struct DftStepArgs {
+  const Cplx<F> *in;   // [outer][Lsum][innerIn][M]
+  Cplx<F> *out;        // [outer][nOut][M]
+  const Cplx<F> *ph;   // [rows][Lsum]
+  const int *groupSrc, *groupFirst, *groupCount;  // per group: source index in `innerIn`, first output, #outputs (<= kDftJT)
+  const int *outRow, *outPos;                     // per output: phase row, position in the out array
+  int M, Lsum, innerIn, nOut;
+};
+
+template <typename F> __global__ __launch_bounds__(256) void partial_dft_kernel(DftStepArgs<F> a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  Cplx<F> *phs = reinterpret_cast<Cplx<F> *>(smem);  // [kDftJT][Lsum], zero rows beyond the group's outputs
+  const int g = blockIdx.y, o = blockIdx.z;
+  const int first = a.groupFirst[g], cnt = a.groupCount[g], src = a.groupSrc[g];
+  for (int i = threadIdx.x; i < kDftJT * a.Lsum; i += 256) {
+    const int j = i / a.Lsum, sI = i - j * a.Lsum;
+    phs[i] = j < cnt ? a.ph[(int64_t)a.outRow[first + j] * a.Lsum + sI] : Cplx<F>{F(0), F(0)};
+  }
+  __syncthreads();
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= a.M) return;
+  Cplx<F> acc[kDftJT];
+#pragma unroll
+  for (int j = 0; j < kDftJT; j++) acc[j] = Cplx<F>{F(0), F(0)};
+  typedef F vec2 __attribute__((ext_vector_type(2)));
+  const Cplx<F> *p = a.in + ((int64_t)o * a.Lsum * a.innerIn + src) * a.M + m;
+  const int64_t step = (int64_t)a.innerIn * a.M;
+#pragma unroll 4
+  for (int sI = 0; sI < a.Lsum; sI++) {
+    const vec2 u = __builtin_nontemporal_load(as_global(reinterpret_cast<const vec2 *>(p + step * sI)));
+    const Cplx<F> v{u.x, u.y};
+#pragma unroll
+    for (int j = 0; j < kDftJT; j++) cmadd(acc[j], v, phs[j * a.Lsum + sI]);
+  }
+#pragma unroll
+  for (int j = 0; j < kDftJT; j++)
+    if (j < cnt) a.out[((int64_t)o * a.nOut + a.outPos[first + j]) * a.M + m] = acc[j];
+}
+
+// the plan: distinct p_x, distinct (p_x, p_y) pairs, and the tables of the three steps
+struct SeparablePlan {
+  std::vector<int> px, py, pz;             // distinct values
+  std::vector<int> pairIpx, pairIpy;       // pairs sorted by ipx
+  std::vector<int> momPair, momIpz;        // per momentum n
+  // per step: groups and outputs
+  std::vector<int> gSrc[3], gFirst[3], gCount[3], oRow[3], oPos[3];
+  int nOut[3];
+};
+
+static int index_of(std::vector<int> &v, int x) {
+  for (size_t i = 0; i < v.size(); i++)
+    if (v[i] == x) return (int)i;
+  v.push_back(x);
+  return (int)v.size() - 1;
+}
+
+static void add_groups(SeparablePlan &P, int st, int src, const std::vector<int> &rows, const std::vector<int> &pos) {
+  for (size_t b = 0; b < rows.size(); b += kDftJT) {
+    const int cnt = (int)std::min<size_t>(kDftJT, rows.size() - b);
+    P.gSrc[st].push_back(src);
+    P.gFirst[st].push_back((int)P.oRow[st].size());
+    P.gCount[st].push_back(cnt);
+    for (int j = 0; j < cnt; j++) {
+      P.oRow[st].push_back(rows[b + j]);
+      P.oPos[st].push_back(pos[b + j]);
+    }
+  }
+}
+
+static void build_plan(const int *mom, int Nmom, SeparablePlan &P) {
+  std::vector<int> momIpx(Nmom), momIpy(Nmom);
+  P.momPair.resize(Nmom);
+  P.momIpz.resize(Nmom);
+  for (int n = 0; n < Nmom; n++) {
+    momIpx[n] = index_of(P.px, mom[3 * n + 0]);
+    momIpy[n] = index_of(P.py, mom[3 * n + 1]);
+    P.momIpz[n] = index_of(P.pz, mom[3 * n + 2]);
+  }
+  // pairs, grouped by ipx
+  for (int ix = 0; ix < (int)P.px.size(); ix++)
+    for (int n = 0; n < Nmom; n++)
+      if (momIpx[n] == ix) {
+        bool seen = false;
+        for (size_t q = 0; q < P.pairIpx.size(); q++) seen = seen || (P.pairIpx[q] == ix && P.pairIpy[q] == momIpy[n]);
+        if (!seen) {
+          P.pairIpx.push_back(ix);
+          P.pairIpy.push_back(momIpy[n]);
+        }
+      }
+  for (int n = 0; n < Nmom; n++)
+    for (size_t q = 0; q < P.pairIpx.size(); q++)
+      if (P.pairIpx[q] == momIpx[n] && P.pairIpy[q] == momIpy[n]) P.momPair[n] = (int)q;
+  // step x: outputs = distinct p_x, one source
+  {
+    std::vector<int> rows, pos;
+    for (int ix = 0; ix < (int)P.px.size(); ix++) {
+      rows.push_back(ix);
+      pos.push_back(ix);
+    }
+    add_groups(P, 0, 0, rows, pos);
+    P.nOut[0] = (int)P.px.size();
+  }
+  // step y: outputs = pairs; source = the pair's ipx
+  for (int ix = 0; ix < (int)P.px.size(); ix++) {
+    std::vector<int> rows, pos;
+    for (size_t q = 0; q < P.pairIpx.size(); q++)
+      if (P.pairIpx[q] == ix) {
+        rows.push_back(P.pairIpy[q]);
+        pos.push_back((int)q);
+      }
+    add_groups(P, 1, ix, rows, pos);
+  }
+  P.nOut[1] = (int)P.pairIpx.size();
+  // step z: outputs = momenta (written at their own index n); source = the momentum's pair
+  for (size_t q = 0; q < P.pairIpx.size(); q++) {
+    std::vector<int> rows, pos;
+    for (int n = 0; n < Nmom; n++)
+      if (P.momPair[n] == (int)q) {
+        rows.push_back(P.momIpz[n]);
+        pos.push_back(n);
+      }
+    add_groups(P, 2, (int)q, rows, pos);
+  }
+  P.nOut[2] = Nmom;
+}
+
+// f_d(q, g) = cos(2 pi phi) + i FTSign sin(2 pi phi), phi = Float(q * g) / Float(totalL_d): the reference's rounding of the
+// phase (lib/mugiq_util_kernels.cu:20-31), one direction at a time
+template <typename F> static void phase_rows(std::vector<Cplx<F>> &out, const std::vector<int> &q, int L, int g0, int totalL, int FTSign) {
+  const double PI = 2.0 * asin(1.0);  // include/util_mugiq.h:7
+  for (size_t r = 0; r < q.size(); r++)
+    for (int x = 0; x < L; x++) {
+      const F phi = static_cast<F>(q[r] * (x + g0)) / static_cast<F>(totalL);
+      const double arg = 2.0 * PI * static_cast<double>(phi);
+      out.push_back(Cplx<F>{static_cast<F>(cos(arg)), static_cast<F>(FTSign) * static_cast<F>(sin(arg))});
+    }
+}
+
+static size_t separable_workspace_elems(const SeparablePlan &P, const int localL[4], int M) {
+  return ((size_t)localL[2] * localL[1] * P.px.size() + (size_t)localL[2] * P.pairIpx.size()) * (size_t)M;
+}
+
+template <typename F>
+static int launch_separable(void *C, const void *A, const int *mom, int Nmom, int FTSign, const int localL[4], const int totalL[4],
+                            const int commCoord[4], int M, void *ws, hipStream_t stream) {
+  SeparablePlan P;
+  build_plan(mom, Nmom, P);
+  // one table: [phases x | phases y | phases z | int tables of the three steps]
+  std::vector<Cplx<F>> ph;
+  size_t phOff[3];
+  const std::vector<int> *qs[3] = {&P.px, &P.py, &P.pz};
+  for (int d = 0; d < 3; d++) {
+    phOff[d] = ph.size();
+    phase_rows<F>(ph, *qs[d], localL[d], (commCoord ? commCoord[d] : 0) * localL[d], totalL[d], FTSign);
+  }
+  std::vector<int> ints;
+  size_t iOff[3][5];
+  for (int st = 0; st < 3; st++) {
+    const std::vector<int> *v[5] = {&P.gSrc[st], &P.gFirst[st], &P.gCount[st], &P.oRow[st], &P.oPos[st]};
+    for (int t = 0; t < 5; t++) {
+      iOff[st][t] = ints.size();
+      ints.insert(ints.end(), v[t]->begin(), v[t]->end());
+    }
+  }
+  const size_t phBytes = (ph.size() * sizeof(Cplx<F>) + 255) / 256 * 256;
+  std::vector<unsigned char> host(phBytes + ints.size() * sizeof(int));
+  memcpy(host.data(), ph.data(), ph.size() * sizeof(Cplx<F>));
+  memcpy(host.data() + phBytes, ints.data(), ints.size() * sizeof(int));
+  void *dev = nullptr;
+  int rc = upload_table(&dev, host.data(), host.size(), stream);
+  if (rc) return rc;
+  const Cplx<F> *ph_d = static_cast<const Cplx<F> *>(dev);
+  const int *int_d = reinterpret_cast<const int *>(static_cast<unsigned char *>(dev) + phBytes);
+
+  Cplx<F> *t1 = static_cast<Cplx<F> *>(ws);
+  Cplx<F> *t2 = t1 + (size_t)localL[2] * localL[1] * P.px.size() * (size_t)M;
+  const Cplx<F> *ins[3] = {static_cast<const Cplx<F> *>(A), t1, t2};
+  Cplx<F> *outs[3] = {t1, t2, static_cast<Cplx<F> *>(C)};
+  const int Lsum[3] = {localL[0], localL[1], localL[2]};
+  const int innerIn[3] = {1, (int)P.px.size(), (int)P.pairIpx.size()};
+  const int outer[3] = {localL[2] * localL[1], localL[2], 1};
+  for (int st = 0; st < 3; st++) {
+    DftStepArgs<F> a;
+    a.in = ins[st];
+    a.out = outs[st];
+    a.ph = ph_d + phOff[st];
+    a.groupSrc = int_d + iOff[st][0];
+    a.groupFirst = int_d + iOff[st][1];
+    a.groupCount = int_d + iOff[st][2];
+    a.outRow = int_d + iOff[st][3];
+    a.outPos = int_d + iOff[st][4];
+    a.M = M;
+    a.Lsum = Lsum[st];
+    a.innerIn = innerIn[st];
+    a.nOut = P.nOut[st];
+    const dim3 grid((M + 255) / 256, (unsigned)P.gSrc[st].size(), outer[st]);
+    const size_t shmem = sizeof(Cplx<F>) * kDftJT * (size_t)Lsum[st];
+    MUGIQ_REQUIRE(shmem <= 64 * 1024 && grid.y <= 65535 && grid.z <= 65535, "performMomentumProjection: lattice / momentum list too large for the separable plan");
+    hipLaunchKernelGGL((partial_dft_kernel<F>), grid, dim3(256), shmem, stream, a);
+    MUGIQ_CHECK_HIP(hipGetLastError());
+  }
+  return MUGIQ_HIP_SUCCESS;
+}
+
 }  // namespace mugiq
 
 using namespace mugiq;
@@ -188,6 +408,36 @@ int mugiq_hip_momentum_projection(void *dataMom_d, const void *dataPosMP_d, cons
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (precision == 8) return launch_momproj<double>(dataMom_d, dataPosMP_d, phaseMatrix_d, g, ws, s);
   return launch_momproj<float>(dataMom_d, dataPosMP_d, phaseMatrix_d, g, ws, s);
+}
+
+size_t mugiq_hip_momentum_projection_separable_workspace(const int *momMatrix_h, int Nmom, const int localL[4], int locT, int nData,
+                                                          int precision) {
+  if (!momMatrix_h || !localL || Nmom < 1 || locT < 1 || nData < 1 || (precision != 4 && precision != 8)) return 0;
+  SeparablePlan P;
+  build_plan(momMatrix_h, Nmom, P);
+  return separable_workspace_elems(P, localL, locT * nData) * 2 * (size_t)precision;
+}
+
+int mugiq_hip_momentum_projection_separable(void *dataMom_d, const void *dataPosMP_d, const int *momMatrix_h, int Nmom, int FTSign,
+                                            const int localL[4], const int totalL[4], const int commCoord[4], int locT, int nData,
+                                            int precision, void *workspace_d, size_t workspace_bytes, void *stream) {
+  const char *who = "performMomentumProjection";
+  MUGIQ_REQUIRE(dataMom_d && dataPosMP_d && momMatrix_h && localL && totalL, "%s: NULL argument", who);
+  MUGIQ_REQUIRE(precision == 4 || precision == 8, "%s: Precision not supported!", who);  // lib/loop_mugiq.cpp:379
+  MUGIQ_REQUIRE(locT >= 1 && nData >= 1 && Nmom >= 1, "%s: invalid sizes locT=%d nData=%d Nmom=%d", who, locT, nData, Nmom);
+  MUGIQ_REQUIRE(FTSign == 1 || FTSign == -1, "%s: FTSign = %d must be +1 or -1", who, FTSign);
+  MUGIQ_REQUIRE((long long)locT * nData < (1LL << 31), "%s: locT*nData overflows int", who);
+  for (int d = 0; d < 3; d++) MUGIQ_REQUIRE(localL[d] > 0 && totalL[d] > 0, "%s: localL / totalL [%d]", who, d);
+  const size_t need = mugiq_hip_momentum_projection_separable_workspace(momMatrix_h, Nmom, localL, locT, nData, precision);
+  void *ws = workspace_d;
+  if (ws == nullptr || workspace_bytes < need) {
+    int st = own_workspace(&ws, need);
+    if (st) return st;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (precision == 8)
+    return launch_separable<double>(dataMom_d, dataPosMP_d, momMatrix_h, Nmom, FTSign, localL, totalL, commCoord, locT * nData, ws, s);
+  return launch_separable<float>(dataMom_d, dataPosMP_d, momMatrix_h, Nmom, FTSign, localL, totalL, commCoord, locT * nData, ws, s);
 }
 
 }  // extern "C"

@@ -121,6 +121,19 @@ def momentumProjection(dataMom_d, dataPosMP_d, phaseMatrix_d, locT, nData, locV3
         int(Nmom), _prec_of(dataPosMP_d), None, 0, _stream()))
 
 
+def momentumProjectionSeparable(dataMom_d, dataPosMP_d, momMatrix, FTSign, localL, totalL, locT, nData, commCoord=(0, 0, 0, 0)):
+    """dataMom[M x Nmom] = sum over the local spatial volume of dataPosMP[M x K] * phase, one direction at a time."""
+    mom = np.ascontiguousarray(np.asarray(momMatrix, dtype=np.int32).reshape(-1))
+    n_mom = mom.size // 3
+    assert dataMom_d.numel() >= locT * nData * n_mom and dataMom_d.dtype == dataPosMP_d.dtype
+    L = (ctypes.c_int * 4)(*[int(x) for x in localL])
+    T = (ctypes.c_int * 4)(*[int(x) for x in totalL])
+    cc = (ctypes.c_int * 4)(*[int(x) for x in commCoord])
+    _lib.check(_lib.load().mugiq_hip_momentum_projection_separable(
+        dataMom_d.data_ptr(), dataPosMP_d.data_ptr(), mom.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n_mom, int(FTSign), L, T, cc,
+        int(locT), int(nData), _prec_of(dataPosMP_d), None, 0, _stream()))
+
+
 def packFaceLayers(faces_d, eVecs, dim, high, layers):
     """[nVec][layers] ghost zones in one buffer (see mugiq_hip_pack_face_layers)."""
     d = desc_array(eVecs)

@@ -234,6 +234,39 @@ def test_momentum_projection_vs_oracle_gemm(hip, prec, locT, nData, L3, Nmom):
     assert rel_err(out.cpu().numpy(), exp) < (1e-13 if prec == 8 else 1e-5)
 
 
+@pytest.mark.parametrize("prec", [8, 4])
+@pytest.mark.parametrize("L,tot,coord,locT,nData,moms", [
+    ((4, 4, 4, 4), (4, 4, 4, 4), (0, 0, 0, 0), 4, 16, "p2le3"),
+    ((8, 6, 4, 8), (8, 6, 4, 8), (0, 0, 0, 0), 8, 32, "p2le9"),
+    ((4, 6, 2, 4), (8, 12, 6, 4), (1, 1, 2, 0), 4, 16, "p2le2"),          # a rank in the middle of a 2 x 2 x 3 spatial grid
+    ((6, 2, 4, 2), (6, 2, 4, 2), (0, 0, 0, 0), 2, 48, "odd")])            # an unsorted list with a repeated momentum
+def test_separable_momentum_projection_matches_phase_matrix_product(hip, prec, L, tot, coord, locT, nData, moms):
+    """mugiq_hip_momentum_projection_separable (one direction at a time) against the reference's formulation: the dense
+    phase matrix of createPhaseMatrixGPU times the reordered loop data (oracle), and against the dense GPU product."""
+    if moms == "odd":
+        mom = [(1, -2, 0), (0, 0, 0), (-3, 1, 2), (1, -2, 0), (2, 2, -1), (0, 5, 0)]
+    else:
+        mom = momenta_p2_le(int(moms[4:]))
+    rng = np.random.default_rng(17)
+    locV3 = L[0] * L[1] * L[2]
+    M = locT * nData
+    cdt = np.complex128 if prec == 8 else np.complex64
+    A = (rng.standard_normal(M * locV3) + 1j * rng.standard_normal(M * locV3)).astype(cdt)
+    tdt = torch.complex128 if prec == 8 else torch.complex64
+    A_d = torch.from_numpy(A).cuda()
+    out = torch.zeros(M * len(mom), dtype=tdt, device="cuda")
+    for FTSign in (1, -1):
+        hip.momentumProjectionSeparable(out, A_d, mom, FTSign, L, tot, locT, nData, coord)
+        ph = orc.phase_matrix(mom, locV3, FTSign, L, tot, coord, dtype=np.float64 if prec == 8 else np.float32)
+        exp = orc.momentum_projection_local(A.astype(np.complex128), ph.astype(np.complex128), locT, nData, locV3, len(mom))
+        assert rel_err(out.cpu().numpy(), exp) < (1e-13 if prec == 8 else 2e-5), (FTSign,)
+        ph_d = torch.empty(locV3 * len(mom), dtype=tdt, device="cuda")
+        hip.createPhaseMatrixGPU(ph_d, mom, locV3, len(mom), FTSign, L, tot, coord)
+        out2 = torch.zeros_like(out)
+        hip.momentumProjection(out2, A_d, ph_d, locT, nData, locV3, len(mom))
+        assert rel_err(out.cpu().numpy(), out2.cpu().numpy()) < (1e-13 if prec == 8 else 2e-5)
+
+
 def test_full_pipeline_ultralocal_and_displaced_vs_oracle(hip):
     """cfg1-like plumbing on the GPU: 8^4... scaled to 4^3x8, N_ev=4, ultra-local + displaced loops,
     reorder, phases, momentum projection -- operator by operator in the reference's order."""

@@ -36,7 +36,9 @@ for name, X, nLoop, Nmom in [("cfg2 32^4 nLoop=1 p2<=9", (32, 32, 32, 32), 1, 12
     mom = torch.empty(X[3] * nData * Nmom, dtype=torch.complex128, device="cuda")
     t_conv = timeit(lambda: hip.convertIdxOrder_mapGamma(mp, pos, nData, nLoop, 2, V // 2, X))
     t_gemm = timeit(lambda: hip.momentumProjection(mom, mp, ph, X[3], nData, locV3, Nmom))
+    t_sep = timeit(lambda: hip.momentumProjectionSeparable(mom, mp, moms, 1, X, X, X[3], nData))
     M, K, N = X[3] * nData, locV3, Nmom
     print(json.dumps({"case": name, "M": M, "K": K, "N": N, "convert_ms": t_conv, "convert_GBps": 2 * 16 * nData * V / t_conv / 1e6,
-                      "gemm_ms": t_gemm, "gemm_TFLOPs": 8.0 * M * K * N / t_gemm / 1e9, "gemm_A_GBps_once": 16.0 * M * K / t_gemm / 1e6}))
+                      "gemm_ms": t_gemm, "gemm_TFLOPs": 8.0 * M * K * N / t_gemm / 1e9, "gemm_A_GBps_once": 16.0 * M * K / t_gemm / 1e6,
+                      "separable_ms": t_sep, "separable_A_GBps_once": 16.0 * M * K / t_sep / 1e6}))
     del pos, mp, ph, mom
