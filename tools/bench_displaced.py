@@ -22,6 +22,7 @@ ap.add_argument("--entries", default="+x:1,3;-x:1,3;+y:1,3;-y:1,3;+z:1,3;-z:1,3;
 ap.add_argument("--plans", default="opt,basic")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--ab-tile", action="store_true", help="alternate MUGIQ_HIP_FUSED_TILE=0/1 in one process (interleaved rounds)")
+ap.add_argument("--momproj", type=int, default=-1, help="also run the momentum projection for all p^2 <= this (whole pipeline)")
 ap.add_argument("--ab-env", default=None, help="NAME=v1,v2,...: alternate an environment knob of the library in one process")
 a = ap.parse_args()
 
@@ -99,9 +100,16 @@ if a.ab_tile:
 for plan in a.plans.split(","):
     prm = hip.MugiqLoopParam(gauge=g, calcType=hip.LOOP_CALC_TYPE_OPT_KERNEL if plan == "opt" else hip.LOOP_CALC_TYPE_BASIC_KERNEL)
     prm.set_displace_entry_string(a.entries)
+    if a.momproj >= 0:
+        r = int(np.sqrt(a.momproj)) + 1
+        moms = [[x, y, z] for x in range(-r, r + 1) for y in range(-r, r + 1) for z in range(-r, r + 1) if x * x + y * y + z * z <= a.momproj]
+        prm.doMomProj, prm.momMatrix, prm.Nmom, prm.FTSign = True, moms, len(moms), -1
     loop = hip.Loop_Mugiq(prm, fields, sig)
     times = []
     for r in range(a.reps):
+        if a.momproj >= 0 and r > 0:          # performMomentumProjection may run once per Loop_Mugiq (as in the reference)
+            loop.close()
+            loop = hip.Loop_Mugiq(prm, fields, sig)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         loop.computeCoarseLoop()
