@@ -45,7 +45,10 @@ def parse():
                     help="8 with --precision 4 = mixed precision (fp32 storage, fp64 accumulation; configs[3])")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the displaced-loop job reported under also_measured (N=1 only)")
+    ap.add_argument("--also-displaced", action="store_true",
+                    help="N=1 only: after the timed region also run the configs[2]-shaped displaced-loop job and report it under "
+                         "also_measured (off by default: it launches the bench kernel with another N_ev, which would blur the "
+                         "per-kernel averages of a rocprofv3 --stats run of the default command)")
     return ap.parse_args()
 
 
@@ -238,7 +241,7 @@ def main():
         err = float(np.max(np.abs(g - cpu_loop)) / np.max(np.abs(cpu_loop)))
         base["max_rel_err_gpu_vs_cpu_on_sample"] = err
         out["cpu_baseline"] = base
-    if rank == 0 and world == 1 and not a.no_extra:
+    if rank == 0 and world == 1 and a.also_displaced:
         del fields, big, loop
         torch.cuda.empty_cache()
         out["also_measured"] = {"displaced_loops": displaced_extra(hip, device)}
