@@ -259,12 +259,12 @@ def test_separable_momentum_projection_matches_phase_matrix_product(hip, prec, L
         hip.momentumProjectionSeparable(out, A_d, mom, FTSign, L, tot, locT, nData, coord)
         ph = orc.phase_matrix(mom, locV3, FTSign, L, tot, coord, dtype=np.float64 if prec == 8 else np.float32)
         exp = orc.momentum_projection_local(A.astype(np.complex128), ph.astype(np.complex128), locT, nData, locV3, len(mom))
-        assert rel_err(out.cpu().numpy(), exp) < (1e-13 if prec == 8 else 2e-5), (FTSign,)
+        assert rel_err(out.cpu().numpy(), exp) < (1e-13 if prec == 8 else 5e-6), (FTSign,)
         ph_d = torch.empty(locV3 * len(mom), dtype=tdt, device="cuda")
         hip.createPhaseMatrixGPU(ph_d, mom, locV3, len(mom), FTSign, L, tot, coord)
         out2 = torch.zeros_like(out)
         hip.momentumProjection(out2, A_d, ph_d, locT, nData, locV3, len(mom))
-        assert rel_err(out.cpu().numpy(), out2.cpu().numpy()) < (1e-13 if prec == 8 else 2e-5)
+        assert rel_err(out.cpu().numpy(), out2.cpu().numpy()) < (1e-13 if prec == 8 else 5e-6)
 
 
 def test_full_pipeline_ultralocal_and_displaced_vs_oracle(hip):
