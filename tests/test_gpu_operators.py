@@ -239,7 +239,8 @@ def test_momentum_projection_vs_oracle_gemm(hip, prec, locT, nData, L3, Nmom):
     ((4, 4, 4, 4), (4, 4, 4, 4), (0, 0, 0, 0), 4, 16, "p2le3"),
     ((8, 6, 4, 8), (8, 6, 4, 8), (0, 0, 0, 0), 8, 32, "p2le9"),
     ((4, 6, 2, 4), (8, 12, 6, 4), (1, 1, 2, 0), 4, 16, "p2le2"),          # a rank in the middle of a 2 x 2 x 3 spatial grid
-    ((6, 2, 4, 2), (6, 2, 4, 2), (0, 0, 0, 0), 2, 48, "odd")])            # an unsorted list with a repeated momentum
+    ((6, 2, 4, 2), (6, 2, 4, 2), (0, 0, 0, 0), 2, 48, "odd"),             # an unsorted list with a repeated momentum
+    ((8, 8, 4, 2), (8, 8, 4, 2), (0, 0, 0, 0), 2, 16, "p2le30")])         # 600+ momenta: many groups per step
 def test_separable_momentum_projection_matches_phase_matrix_product(hip, prec, L, tot, coord, locT, nData, moms):
     """mugiq_hip_momentum_projection_separable (one direction at a time) against the reference's formulation: the dense
     phase matrix of createPhaseMatrixGPU times the reordered loop data (oracle), and against the dense GPU product."""
