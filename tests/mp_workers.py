@@ -110,7 +110,7 @@ def cpu_worker(rank, world, port, grid):
     dist.destroy_process_group()
 
 
-def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8)):
+def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8), seed=None):
     """The C++ driver on every rank (all on cuda:0), halos and FT reduction through the comm callbacks."""
     import torch
     from util import orc, momenta_p2_le, rel_err
@@ -122,6 +122,16 @@ def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8)):
     # ... and "+t:5" after it has a computed opposite-sign source of the same length, which the OPT plan must NOT
     # reflect on a t-partitioned grid (length > local extent) but may on the others
     disp = (["+t", "-t", "+z", "-z", "+x", "-y", "-t", "+y", "+t"], [1, 2, 1, 1, 1, 2, 5, 1, 5], [3, 2, 2, 1, 1, 2, 5, 3, 5])
+    if seed is not None:                                                      # seeded random entry list (same on every rank)
+        r = np.random.default_rng(seed)
+        n = int(r.integers(2, 7))
+        names, lo, hi = [], [], []
+        for _ in range(n):
+            names.append("+-"[int(r.integers(2))] + "xyzt"[int(r.integers(4))])
+            a_, b_ = sorted(int(v) for v in r.integers(1, 6, size=2))
+            lo.append(a_)
+            hi.append(b_)
+        disp = (names, lo, hi)
     moms = momenta_p2_le(2)
     FTSign = 1
     nev = 3

@@ -1,6 +1,8 @@
 """GPU tests of the C++ driver (Loop_Mugiq / Displace mirror): slot bookkeeping, both execution plans
 (BASIC = the reference's launch sequence, OPT = batched + fused), momentum projection, and the
 domain-decomposed run (2 ranks sharing the one GPU of the box, gloo transport through the comm callbacks)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -150,6 +152,16 @@ def test_two_rank_driver_interior_boundary_tiles(grid, G, prec, order):
     """Local extent 8 along the partitioned axis: the tiled kernel runs its INTERIOR tiles while the halo is in flight and
     its BOUNDARY tiles afterwards (two tiles along the axis)."""
     mp.spawn(mp_workers.gpu_worker, args=(2, free_port(), grid, prec, order, 2, G), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MUGIQ_TEST_MP_SEEDS", 4))))
+def test_two_rank_driver_random_entries(seed):
+    """Seeded random entry lists (both signs, lengths 1..5 against a local extent of 4: reflected entries with and without
+    halo, lengths past the neighbour) on a randomly chosen partitioned axis, OPT plan."""
+    axis = (seed * 7 + 3) % 4
+    grid = tuple(2 if d == axis else 1 for d in range(4))
+    prec, order = [(8, 2), (4, 4), (8, 4), (4, 2)][seed % 4]
+    mp.spawn(mp_workers.gpu_worker, args=(2, free_port(), grid, prec, order, 1, (8, 8, 8, 8), 9000 + seed), nprocs=2, join=True)
 
 
 def test_four_rank_driver_z_and_t_partitioned_on_one_gpu():
@@ -314,7 +326,7 @@ def _random_case(seed):
     return X, prec, order, nev, ";".join(ents), pad, gpad
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MUGIQ_TEST_SEEDS", 48))))   # MUGIQ_TEST_SEEDS=N widens the sweep
 def test_driver_random_shapes_both_fused_plans(hip, seed, monkeypatch):
     """Seeded random lattice shapes (extents from 2 to 12), storage types, eigenvector counts and displacement entries
     (lengths past the extent, start > stop) through the OPT plan with the tiled and the streaming kernels."""
