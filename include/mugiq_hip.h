@@ -257,6 +257,14 @@ int mugiq_hip_momentum_projection_separable(void *dataMom_d, const void *dataPos
                                             int locT, int nData, int precision, void *workspace_d, size_t workspace_bytes,
                                             void *stream);
 
+/* a9 + a10 in one call (new): dataMom_d[M x Nmom] from the even-odd position-space buffer dataPos_d ([nData][V], the input
+ * of convertIdxOrder_mapGamma).  The reorder with the G -> g5 G map and the sum over x happen in one kernel, so the
+ * reordered copy dataPosMP is neither written nor read; then the y and z steps of the separable projection.
+ * Workspace as for mugiq_hip_momentum_projection_separable. */
+int mugiq_hip_convert_and_project(void *dataMom_d, const void *dataPos_d, int nData, int nLoop, const int *momMatrix_h, int Nmom,
+                                  int FTSign, const int localL[4], const int totalL[4], const int commCoord[4], int precision,
+                                  void *workspace_d, size_t workspace_bytes, void *stream);
+
 /* ==== f2: MG coarse path -- Loop_Mugiq::prolongateEvec (lib/loop_mugiq.cpp:277-319) = QUDA Transfer::P ============== */
 
 /* A coarse-grid colour-spinor in QUDA's FLOAT2 order (what Eigsolve_Mugiq hands over when computeCoarse is set,

@@ -92,6 +92,8 @@ SIGNATURES = {
     "mugiq_hip_momentum_projection_separable_workspace": (ctypes.c_size_t, [_I4, ctypes.c_int, _I4, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "mugiq_hip_momentum_projection_separable": (ctypes.c_int, [_VP, _VP, _I4, ctypes.c_int, ctypes.c_int, _I4, _I4, _I4, ctypes.c_int,
                                                                ctypes.c_int, ctypes.c_int, _VP, ctypes.c_size_t, _VP]),
+    "mugiq_hip_convert_and_project": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, _I4, ctypes.c_int, ctypes.c_int, _I4, _I4, _I4,
+                                                     ctypes.c_int, _VP, ctypes.c_size_t, _VP]),
     "mugiq_hip_pack_face_layers": (ctypes.c_int, [_VP, _SP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP]),
     "mugiq_hip_reflect_displaced_loop": (ctypes.c_int, [_VP, _VP, _VP, _I4, ctypes.c_int, ctypes.c_int, ctypes.c_int, _I4, ctypes.c_int, _VP]),
     "mugiq_hip_pack_loop_layers": (ctypes.c_int, [_VP, _VP, _I4, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP]),

@@ -404,23 +404,38 @@ static void destroy_pool(MugiqHipLoop *lp) {
 static int momentum_projection(MugiqHipLoop *lp) {
   if (lp->momProjDone) return set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "performMomentumProjection: Not supposed to be called more than once!!");
   int st;
-  if ((st = mugiq_hip_convert_idx_order_map_gamma(lp->dataPosMP_d, lp->dataPos_d, lp->nData, lp->nLoop, 2, lp->volumeCB,
-                                                  lp->localL, lp->loopPrecision, lp->stream)))  // :343-344
-    return st;
   if (lp->calcType == MUGIQ_HIP_LOOP_CALC_TYPE_BASIC_KERNEL) {
-    // the reference's formulation: one dense product with the phase matrix of createPhaseMatrixGPU   :363-378
+    // the reference's sequence: reorder (:343-344), then one dense product with the phase matrix of createPhaseMatrixGPU (:363-378)
+    if (!lp->dataPosMP_d && (st = dev_alloc(lp, &lp->dataPosMP_d, (size_t)lp->nElemPosLoc * lp->loopBytes(), true))) return st;
+    if ((st = mugiq_hip_convert_idx_order_map_gamma(lp->dataPosMP_d, lp->dataPos_d, lp->nData, lp->nLoop, 2, lp->volumeCB,
+                                                    lp->localL, lp->loopPrecision, lp->stream)))
+      return st;
     if ((st = mugiq_hip_momentum_projection(lp->dataMom_d, lp->dataPosMP_d, lp->phaseMatrix_d, lp->locT, lp->nData, lp->locV3,
                                             lp->Nmom, lp->loopPrecision, nullptr, 0, lp->stream)))
       return st;
   } else {
-    // OPT: the same sums taken one spatial direction at a time (csrc/momproj.hip)
+    // OPT: reorder + gamma5 map + sum over x in one kernel, then the y and z sums (csrc/momproj.hip); no reordered copy
     int coord[4] = {0, 0, 0, 0};
     if (lp->haveComm)
       for (int d = 0; d < 4; d++) coord[d] = lp->comm.coord[d];
-    if ((st = mugiq_hip_momentum_projection_separable(lp->dataMom_d, lp->dataPosMP_d, lp->momMatrix.data(), lp->Nmom, lp->FTSign,
-                                                      lp->localL, lp->totalL, coord, lp->locT, lp->nData, lp->loopPrecision, nullptr,
-                                                      0, lp->stream)))
-      return st;
+    std::vector<int> px;  // distinct p_x: the phase rows of the x step
+    for (int n = 0; n < lp->Nmom; n++)
+      if (std::find(px.begin(), px.end(), lp->momMatrix[3 * n]) == px.end()) px.push_back(lp->momMatrix[3 * n]);
+    const size_t tileBytes = lp->loopBytes() * ((size_t)2 * lp->localL[3] * (lp->localL[0] + 1) + px.size() * (size_t)lp->localL[0]);
+    if (tileBytes <= 64 * 1024 && lp->localL[2] <= 65535 && lp->nData <= 65535) {
+      if ((st = mugiq_hip_convert_and_project(lp->dataMom_d, lp->dataPos_d, lp->nData, lp->nLoop, lp->momMatrix.data(), lp->Nmom, lp->FTSign,
+                                              lp->localL, lp->totalL, coord, lp->loopPrecision, nullptr, 0, lp->stream)))
+        return st;
+    } else {  // a lattice whose (x, t) rows do not fit the LDS tile: reorder, then the three separable steps
+      if (!lp->dataPosMP_d && (st = dev_alloc(lp, &lp->dataPosMP_d, (size_t)lp->nElemPosLoc * lp->loopBytes(), true))) return st;
+      if ((st = mugiq_hip_convert_idx_order_map_gamma(lp->dataPosMP_d, lp->dataPos_d, lp->nData, lp->nLoop, 2, lp->volumeCB,
+                                                      lp->localL, lp->loopPrecision, lp->stream)))
+        return st;
+      if ((st = mugiq_hip_momentum_projection_separable(lp->dataMom_d, lp->dataPosMP_d, lp->momMatrix.data(), lp->Nmom, lp->FTSign,
+                                                        lp->localL, lp->totalL, coord, lp->locT, lp->nData, lp->loopPrecision, nullptr,
+                                                        0, lp->stream)))
+        return st;
+    }
   }
   const size_t locBytes = (size_t)lp->nElemMomLoc * lp->loopBytes();
   MUGIQ_CHECK_HIP(hipMemcpyAsync(lp->dataMom_h, lp->dataMom_d, locBytes, hipMemcpyDeviceToHost, lp->stream));  // :386
@@ -637,7 +652,8 @@ int mugiq_hip_loop_create(MugiqHipLoop **out, const MugiqHipLoopParam *p, const 
     }
     if ((st = dev_alloc(lp, &lp->phaseMatrix_d, (size_t)lp->nElemPhMat * cb, true))) return fail(st);
     if ((st = dev_alloc(lp, &lp->dataMom_d, (size_t)lp->nElemMomLoc * cb, true))) return fail(st);
-    if ((st = dev_alloc(lp, &lp->dataPosMP_d, (size_t)lp->nElemPosLoc * cb, true))) return fail(st);
+    // dataPosMP_d (the reordered copy of the loop data, lib/loop_mugiq.cpp:143) is allocated on first use: only the BASIC
+    // plan forms it
   }
   // copyGammaToConstMem :162-167, createPhaseMatrix :171-178
   if ((st = mugiq_hip_copy_gamma_coeff_to_symbol(lp->precision))) return fail(st);

@@ -209,6 +209,56 @@ template <typename F> __global__ __launch_bounds__(256) void partial_dft_kernel(
     if (j < cnt) a.out[((int64_t)o * a.nOut + a.outPos[first + j]) * a.M + m] = acc[j];
 }
 
+// Step x taken straight from the even-odd position-space buffer: the reorder of convertIdxOrder_mapGamma
+// (lib/mugiq_util_kernels.cu:59-99: tid = x_cb + volumeCB*parity -> time-major rows, gamma -> g5 gamma with sign) and the sum
+// over x in one pass, so the reordered copy (as large as the loop data itself) is neither written nor read.
+//   T1[(z*Ly + y)*nPx + ipx][t + Lt*idataTo] = s(ig) * sum_x dataPos[idataFrom][x,y,z,t] * f_x(ipx, x)
+// One workgroup per (pair of y rows, z, idataFrom): the rows x = 0..Lx-1 of both y and all t land in LDS (runs of Lx
+// checkerboard entries per parity and t), then lane <-> (y, ipx, t) sums its row.
+constexpr int kEoYG = 2;  // y rows per workgroup (their checkerboard entries are adjacent)
+
+template <typename F> struct EoDftArgs {
+  const Cplx<F> *in;   // dataPos [nData][2*volumeCB]
+  Cplx<F> *out;        // T1 [Lz*Ly][nPx][M]
+  const Cplx<F> *ph;   // [nPx][Lx]
+  int X[4];
+  int volumeCB, nPx, M;
+};
+
+template <typename F> __global__ __launch_bounds__(256) void eo_dft_x_kernel(EoDftArgs<F> a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int Lx = a.X[0], Ly = a.X[1], Lz = a.X[2], Lt = a.X[3], ld = Lx + 1;  // padded rows: lanes walk t at a fixed x
+  Cplx<F> *tile = reinterpret_cast<Cplx<F> *>(smem);                         // [kEoYG][Lt][Lx + 1]
+  Cplx<F> *phs = tile + kEoYG * Lt * ld;                                     // [nPx][Lx]
+  const int y0 = blockIdx.x * kEoYG, z = blockIdx.y, idataFrom = blockIdx.z;
+  const int ig = idataFrom & 15;
+  const int idataTo = (15 - ig) + (idataFrom - ig);  // gammaMap->index[ig] + N_GAMMA_*iL   :89
+  const F sign = (F)kGammaMapSign[ig];               // gammaMap->sign[ig]                    :93
+  const Cplx<F> *src = a.in + (int64_t)idataFrom * 2 * a.volumeCB;
+  for (int i = threadIdx.x; i < a.nPx * Lx; i += 256) phs[i] = a.ph[i];
+  // per (t, parity): the kEoYG * Lx/2 checkerboard entries of rows y0, y0+1 are contiguous
+  const int hx = Lx >> 1, run = kEoYG * hx;
+  typedef F vec2 __attribute__((ext_vector_type(2)));
+  for (int i = threadIdx.x; i < 2 * Lt * run; i += 256) {
+    const int r = i % run, tp = i / run, pty = tp & 1, t = tp >> 1;
+    const int yy = r / hx, xh = r - yy * hx, y = y0 + yy;
+    const int x = 2 * xh + ((pty - (y + z + t)) & 1);
+    const int64_t x_cb = ((((int64_t)t * Lz + z) * Ly + y0) * Lx >> 1) + r;
+    const vec2 u = __builtin_nontemporal_load(as_global(reinterpret_cast<const vec2 *>(src + (int64_t)pty * a.volumeCB + x_cb)));
+    tile[(yy * Lt + t) * ld + x] = Cplx<F>{sign * u.x, sign * u.y};
+  }
+  __syncthreads();
+  const int nOutB = kEoYG * a.nPx * Lt;
+  for (int o = threadIdx.x; o < nOutB; o += 256) {
+    const int t = o % Lt, rest = o / Lt, ipx = rest % a.nPx, yy = rest / a.nPx;
+    const Cplx<F> *row = tile + (yy * Lt + t) * ld;
+    const Cplx<F> *f = phs + ipx * Lx;
+    Cplx<F> acc{F(0), F(0)};
+    for (int x = 0; x < Lx; x++) cmadd(acc, row[x], f[x]);
+    a.out[((int64_t)(z * Ly + y0 + yy) * a.nPx + ipx) * a.M + t + Lt * idataTo] = acc;
+  }
+}
+
 // the plan: distinct p_x, distinct (p_x, p_y) pairs, and the tables of the three steps
 struct SeparablePlan {
   std::vector<int> px, py, pz;             // distinct values
@@ -313,8 +363,8 @@ static size_t separable_workspace_elems(const SeparablePlan &P, const int localL
 }
 
 template <typename F>
-static int launch_separable(void *C, const void *A, const int *mom, int Nmom, int FTSign, const int localL[4], const int totalL[4],
-                            const int commCoord[4], int M, void *ws, hipStream_t stream) {
+static int launch_separable(void *C, const void *A, const void *dataPosEO, int nData, const int *mom, int Nmom, int FTSign,
+                            const int localL[4], const int totalL[4], const int commCoord[4], int M, void *ws, hipStream_t stream) {
   SeparablePlan P;
   build_plan(mom, Nmom, P);
   // one table: [phases x | phases y | phases z | int tables of the three steps]
@@ -351,7 +401,27 @@ static int launch_separable(void *C, const void *A, const int *mom, int Nmom, in
   const int Lsum[3] = {localL[0], localL[1], localL[2]};
   const int innerIn[3] = {1, (int)P.px.size(), (int)P.pairIpx.size()};
   const int outer[3] = {localL[2] * localL[1], localL[2], 1};
-  for (int st = 0; st < 3; st++) {
+  int firstStep = 0;
+  if (dataPosEO != nullptr) {  // step x straight from the even-odd buffer (A, the reordered copy, is not needed)
+    const size_t shmem = sizeof(Cplx<F>) * ((size_t)kEoYG * localL[3] * (localL[0] + 1) + P.px.size() * (size_t)localL[0]);
+    MUGIQ_REQUIRE(shmem <= 64 * 1024 && localL[2] <= 65535 && nData <= 65535, "performMomentumProjection: lattice too large for the fused reorder + x step");
+    EoDftArgs<F> e;
+    e.in = static_cast<const Cplx<F> *>(dataPosEO);
+    e.out = t1;
+    e.ph = ph_d + phOff[0];
+    long long vol = 1;
+    for (int d = 0; d < 4; d++) {
+      e.X[d] = localL[d];
+      vol *= localL[d];
+    }
+    e.volumeCB = (int)(vol / 2);
+    e.nPx = (int)P.px.size();
+    e.M = M;
+    hipLaunchKernelGGL((eo_dft_x_kernel<F>), dim3(localL[1] / kEoYG, localL[2], nData), dim3(256), shmem, stream, e);
+    MUGIQ_CHECK_HIP(hipGetLastError());
+    firstStep = 1;
+  }
+  for (int st = firstStep; st < 3; st++) {
     DftStepArgs<F> a;
     a.in = ins[st];
     a.out = outs[st];
@@ -436,8 +506,35 @@ int mugiq_hip_momentum_projection_separable(void *dataMom_d, const void *dataPos
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (precision == 8)
-    return launch_separable<double>(dataMom_d, dataPosMP_d, momMatrix_h, Nmom, FTSign, localL, totalL, commCoord, locT * nData, ws, s);
-  return launch_separable<float>(dataMom_d, dataPosMP_d, momMatrix_h, Nmom, FTSign, localL, totalL, commCoord, locT * nData, ws, s);
+    return launch_separable<double>(dataMom_d, dataPosMP_d, nullptr, nData, momMatrix_h, Nmom, FTSign, localL, totalL, commCoord, locT * nData, ws, s);
+  return launch_separable<float>(dataMom_d, dataPosMP_d, nullptr, nData, momMatrix_h, Nmom, FTSign, localL, totalL, commCoord, locT * nData, ws, s);
+}
+
+int mugiq_hip_convert_and_project(void *dataMom_d, const void *dataPos_d, int nData, int nLoop, const int *momMatrix_h, int Nmom, int FTSign,
+                                  const int localL[4], const int totalL[4], const int commCoord[4], int precision, void *workspace_d,
+                                  size_t workspace_bytes, void *stream) {
+  const char *who = "performMomentumProjection";
+  MUGIQ_REQUIRE(dataMom_d && dataPos_d && momMatrix_h && localL && totalL, "%s: NULL argument", who);
+  MUGIQ_REQUIRE(nData == nLoop * 16 && nLoop >= 1, "%s: This function assumes that nData = nLoop * NGamma", who);  // lib/contract_wrappers.cu:138
+  MUGIQ_REQUIRE(precision == 4 || precision == 8, "%s: Precision not supported!", who);
+  MUGIQ_REQUIRE(Nmom >= 1 && (FTSign == 1 || FTSign == -1), "%s: Nmom = %d, FTSign = %d", who, Nmom, FTSign);
+  long long vol = 1;
+  for (int d = 0; d < 4; d++) {
+    MUGIQ_REQUIRE(localL[d] > 0 && (localL[d] & 1) == 0 && totalL[d] > 0, "%s: localL[%d] = %d must be positive and even", who, d, localL[d]);
+    vol *= localL[d];
+  }
+  MUGIQ_REQUIRE(vol < (1LL << 31) && (long long)localL[3] * nData < (1LL << 31), "%s: local volume overflows int", who);
+  const int locT = localL[3];
+  const size_t need = mugiq_hip_momentum_projection_separable_workspace(momMatrix_h, Nmom, localL, locT, nData, precision);
+  void *ws = workspace_d;
+  if (ws == nullptr || workspace_bytes < need) {
+    int st = own_workspace(&ws, need);
+    if (st) return st;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (precision == 8)
+    return launch_separable<double>(dataMom_d, nullptr, dataPos_d, nData, momMatrix_h, Nmom, FTSign, localL, totalL, commCoord, locT * nData, ws, s);
+  return launch_separable<float>(dataMom_d, nullptr, dataPos_d, nData, momMatrix_h, Nmom, FTSign, localL, totalL, commCoord, locT * nData, ws, s);
 }
 
 }  // extern "C"

@@ -134,6 +134,16 @@ def momentumProjectionSeparable(dataMom_d, dataPosMP_d, momMatrix, FTSign, local
         int(locT), int(nData), _prec_of(dataPosMP_d), None, 0, _stream()))
 
 
+def convertAndProject(dataMom_d, dataPos_d, nData, nLoop, momMatrix, FTSign, localL, totalL, commCoord=(0, 0, 0, 0)):
+    """reorder + gamma5 map + momentum projection from the even-odd buffer in one go (see mugiq_hip_convert_and_project)."""
+    mom = np.ascontiguousarray(np.asarray(momMatrix, dtype=np.int32).reshape(-1))
+    n_mom = mom.size // 3
+    assert dataMom_d.numel() >= localL[3] * nData * n_mom and dataMom_d.dtype == dataPos_d.dtype
+    _lib.check(_lib.load().mugiq_hip_convert_and_project(
+        dataMom_d.data_ptr(), dataPos_d.data_ptr(), int(nData), int(nLoop), mom.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n_mom,
+        int(FTSign), _lib.int4(localL), _lib.int4(totalL), _lib.int4(commCoord), _prec_of(dataPos_d), None, 0, _stream()))
+
+
 def packFaceLayers(faces_d, eVecs, dim, high, layers):
     """[nVec][layers] ghost zones in one buffer (see mugiq_hip_pack_face_layers)."""
     d = desc_array(eVecs)

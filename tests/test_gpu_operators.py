@@ -270,6 +270,28 @@ def test_separable_momentum_projection_matches_phase_matrix_product(hip, prec, L
         assert rel_err(out.cpu().numpy(), out2.cpu().numpy()) < (1e-13 if prec == 8 else 5e-6)
 
 
+@pytest.mark.parametrize("prec", [8, 4])
+@pytest.mark.parametrize("X,nLoop,coord,tot", [((4, 4, 4, 4), 1, (0, 0, 0, 0), None), ((6, 4, 2, 8), 3, (0, 0, 0, 0), None),
+                                               ((8, 8, 8, 4), 2, (1, 0, 1, 0), (16, 8, 24, 8)), ((12, 6, 4, 2), 5, (0, 0, 0, 0), None)])
+def test_convert_and_project_in_one_call(hip, prec, X, nLoop, coord, tot):
+    """mugiq_hip_convert_and_project (reorder + gamma5 map + x step in one kernel, then y and z) against the reference's
+    sequence on the oracle: convertIdxOrder_mapGamma, createPhaseMatrix, dense product."""
+    tot = tot or X
+    rng = np.random.default_rng(31)
+    V = int(np.prod(X))
+    nData = 16 * nLoop
+    cdt = _np_c(prec)
+    pos = (rng.standard_normal(nData * V) + 1j * rng.standard_normal(nData * V)).astype(cdt)
+    mom = momenta_p2_le(5)
+    locV3 = X[0] * X[1] * X[2]
+    out = torch.zeros(X[3] * nData * len(mom), dtype=torch.complex128 if prec == 8 else torch.complex64, device="cuda")
+    hip.convertAndProject(out, torch.from_numpy(pos).cuda(), nData, nLoop, mom, -1, X, tot, coord)
+    mp_ = orc.convert_idx_order_map_gamma(pos.astype(np.complex128), nData, nLoop, 2, V // 2, X)
+    ph = orc.phase_matrix(mom, locV3, -1, X, tot, coord, dtype=np.float64 if prec == 8 else np.float32)
+    exp = orc.momentum_projection_local(mp_, ph.astype(np.complex128), X[3], nData, locV3, len(mom))
+    assert rel_err(out.cpu().numpy(), exp) < (1e-13 if prec == 8 else 5e-6)
+
+
 def test_full_pipeline_ultralocal_and_displaced_vs_oracle(hip):
     """cfg1-like plumbing on the GPU: 8^4... scaled to 4^3x8, N_ev=4, ultra-local + displaced loops,
     reorder, phases, momentum projection -- operator by operator in the reference's order."""
