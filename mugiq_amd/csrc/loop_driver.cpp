@@ -448,10 +448,7 @@ static int momentum_projection(MugiqHipLoop *lp) {
       return set_error(MUGIQ_HIP_ERROR_HIP, "gather_time callback failed with status %d", st);
     if ((st = lp->comm.bcast(lp->comm.ctx, lp->dataMom_bcast, 2 * (size_t)lp->nElemMomTot, lp->loopPrecision)))  // :424
       return set_error(MUGIQ_HIP_ERROR_HIP, "bcast callback failed with status %d", st);
-  } else {
-    memcpy(lp->dataMom, lp->dataMom_h, locBytes);
-    memcpy(lp->dataMom_bcast, lp->dataMom, locBytes);
-  }
+  }  // (one process: dataMom and dataMom_bcast alias dataMom_h)
   lp->momProjDone = true;
   return MUGIQ_HIP_SUCCESS;
 }
@@ -643,9 +640,18 @@ int mugiq_hip_loop_create(MugiqHipLoop **out, const MugiqHipLoopParam *p, const 
   const size_t cb = lp->loopBytes();
   if ((st = dev_alloc(lp, &lp->dataPos_d, (size_t)lp->nElemPosLoc * cb, true))) return fail(st);
   if (lp->doMomProj) {
-    lp->dataMom_bcast = calloc((size_t)lp->nElemMomTot, cb);
-    lp->dataMom_h = calloc((size_t)lp->nElemMomLoc, cb);
-    lp->dataMom = calloc((size_t)lp->nElemMomLoc, cb);
+    // the device -> host landing buffer is pinned (a pageable copy of ~20 MB costs several ms, more than the projection)
+    if (hipHostMalloc(&lp->dataMom_h, (size_t)lp->nElemMomLoc * cb, hipHostMallocDefault) != hipSuccess) lp->dataMom_h = nullptr;
+    else memset(lp->dataMom_h, 0, (size_t)lp->nElemMomLoc * cb);
+    if (lp->haveComm && lp->comm.size > 1) {
+      lp->dataMom_bcast = calloc((size_t)lp->nElemMomTot, cb);
+      lp->dataMom = calloc((size_t)lp->nElemMomLoc, cb);
+    } else {
+      // one process: the reduced (dataMom) and the gathered + broadcast (dataMom_bcast) arrays ARE the local one -- aliases
+      // instead of two more copies through freshly mapped pages (6 ms for 19 MB)
+      lp->dataMom = lp->dataMom_h;
+      lp->dataMom_bcast = lp->dataMom_h;
+    }
     if (!lp->dataMom_bcast || !lp->dataMom_h || !lp->dataMom) {
       set_error(MUGIQ_HIP_ERROR_HIP, "%s: Could not allocate host buffers dataMom*", who);
       return fail(MUGIQ_HIP_ERROR_HIP);
@@ -947,9 +953,9 @@ int mugiq_hip_loop_write_hdf5(MugiqHipLoop *lp) {
 int mugiq_hip_loop_destroy(MugiqHipLoop *lp) {  // freeDataMemory, lib/loop_mugiq.cpp:182-229
   if (!lp) return MUGIQ_HIP_SUCCESS;
   destroy_pool(lp);
-  free(lp->dataMom_bcast);
-  free(lp->dataMom_h);
-  free(lp->dataMom);
+  if (lp->dataMom_bcast != lp->dataMom_h) free(lp->dataMom_bcast);
+  if (lp->dataMom_h) (void)hipHostFree(lp->dataMom_h);
+  if (lp->dataMom != lp->dataMom_h) free(lp->dataMom);
   free(lp->dataPos);
   if (lp->fineStore) (void)hipFree(lp->fineStore);
   for (auto &h : lp->halo) {
