@@ -215,6 +215,9 @@ int mugiq_hip_displaced_loop_contraction_fused_mixed(void *loopData_d, int loopP
 #define MUGIQ_HIP_REGION_ALL 0
 #define MUGIQ_HIP_REGION_INTERIOR 1
 #define MUGIQ_HIP_REGION_BOUNDARY 2
+/* OR-ed into `region`: the addressed sites of the slots are WRITTEN instead of accumulated into -- the caller vouches that
+ * they hold nothing yet and saves the memset of the slots and the read half of the read-modify-write. */
+#define MUGIQ_HIP_REGION_OVERWRITE 0x100
 int mugiq_hip_displaced_loop_contraction_fused_region(void *loopData_d, int loopPrecision,
                                                       const MugiqHipSpinorField *eVecs_h, const double *sigma_h, int nVec,
                                                       const void *const *pathLinkFields_h, const int *kValues_h, int nK,

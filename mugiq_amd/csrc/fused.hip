@@ -27,6 +27,7 @@ constexpr int kFusedMaxSlots = 4;
 template <typename F, typename A> struct FusedArgs {
   Cplx<A> *loop;            // first slot handled by this launch
   int64_t slot_stride;      // complex elements between consecutive slots (16*V)
+  int overwrite;            // store instead of accumulate (MUGIQ_HIP_REGION_OVERWRITE)
   const void *const *L;     // device table of eigenvector bodies
   const A *inv_sigma;       // device [nVec]
   int nVec;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(64 * kFusedMaxSlots) void fused_displaced_contract_
 #pragma unroll
     for (int s2 = 0; s2 < 4; s2++) add_phase(t, kGammaPhase[iG][s2], acc[s2 * 4 + kGammaColumn[iG][s2]]);
     Cplx<A> *out = loop + (int64_t)V * iG + site;
-    Cplx<A> o = *out;
+    Cplx<A> o = a.overwrite ? Cplx<A>{A(0), A(0)} : *out;
     o.re += t.re;
     o.im += t.im;
     *out = o;
@@ -274,6 +275,8 @@ static int fused_entry(void *loop_d, const MugiqHipSpinorField *ev, const double
       return tile_entry<F, A, ORDER>(loop_d, ev, sigma, nVec, E_d, kvals, nK, dir, sign, partitioned, ghost_d, layers, region, stream);
   }
   // the streaming kernel has no interior / boundary split: when the dimension is partitioned it counts as boundary
+  const int overwrite = (region & MUGIQ_HIP_REGION_OVERWRITE) ? 1 : 0;
+  region &= 0xff;
   if (region == MUGIQ_HIP_REGION_INTERIOR && partitioned) return MUGIQ_HIP_SUCCESS;
   if (region == MUGIQ_HIP_REGION_BOUNDARY && !partitioned) return MUGIQ_HIP_SUCCESS;
   const size_t ptr_bytes = sizeof(void *) * (size_t)nVec;
@@ -290,6 +293,7 @@ static int fused_entry(void *loop_d, const MugiqHipSpinorField *ev, const double
   if (st) return st;
   FusedArgs<F, A> a;
   a.slot_stride = (int64_t)16 * 2 * ev[0].volumeCB;
+  a.overwrite = overwrite;
   a.L = reinterpret_cast<const void *const *>(dev);
   a.inv_sigma = reinterpret_cast<const A *>(static_cast<unsigned char *>(dev) + ptr_bytes);
   a.nVec = nVec;
@@ -370,8 +374,9 @@ int mugiq_hip_displaced_loop_contraction_fused_region(void *loopData_d, int loop
                                                       const int commDim[4], const void *ghostLayers_d, int layers, int region,
                                                       void *stream) {
   const char *who = "mugiq_hip_displaced_loop_contraction_fused";
-  MUGIQ_REQUIRE(region == MUGIQ_HIP_REGION_ALL || region == MUGIQ_HIP_REGION_INTERIOR || region == MUGIQ_HIP_REGION_BOUNDARY,
+  MUGIQ_REQUIRE((region & 0xff) == MUGIQ_HIP_REGION_ALL || (region & 0xff) == MUGIQ_HIP_REGION_INTERIOR || (region & 0xff) == MUGIQ_HIP_REGION_BOUNDARY,
                 "%s: invalid region %d", who, region);
+  MUGIQ_REQUIRE((region & ~(0xff | MUGIQ_HIP_REGION_OVERWRITE)) == 0, "%s: invalid region flags %d", who, region);
   MUGIQ_REQUIRE(loopData_d && eVecs_h && sigma_h && pathLinkFields_h && kValues_h, "%s: NULL argument", who);
   MUGIQ_REQUIRE(nVec >= 1 && nK >= 1, "%s: nVec = %d, nK = %d must be >= 1", who, nVec, nK);
   MUGIQ_REQUIRE(dispDir >= 0 && dispDir < 4 && (dispSign == 0 || dispSign == 1), "%s: Got invalid dispDir and/or dispSign.", who);
@@ -388,7 +393,7 @@ int mugiq_hip_displaced_loop_contraction_fused_region(void *loopData_d, int loop
     MUGIQ_REQUIRE(pathLinkFields_h[i] != nullptr, "%s: pathLinkFields_h[%d] is NULL", who, i);
     if (kValues_h[i] > kmax) kmax = kValues_h[i];
   }
-  if (part && region != MUGIQ_HIP_REGION_INTERIOR) {
+  if (part && (region & 0xff) != MUGIQ_HIP_REGION_INTERIOR) {
     MUGIQ_REQUIRE(ghostLayers_d != nullptr, "%s: dim %d is partitioned but ghostLayers_d is NULL (halo exchange missing)", who,
                   dispDir);
     MUGIQ_REQUIRE(layers >= kmax && layers <= eVecs_h[0].X[dispDir],

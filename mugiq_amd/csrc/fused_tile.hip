@@ -52,6 +52,7 @@ template <typename F, typename A> struct TileArgs {
   int jtCount;
   int tileBytes;  // LDS bytes of the two staging tiles
   int blockOrder; // workgroup -> tile map (see the kernel)
+  int overwrite;  // store instead of accumulate (MUGIQ_HIP_REGION_OVERWRITE)
 };
 
 // complex-element offset of component `comp` at checkerboard index idx inside one parity block of a field / ghost zone
@@ -351,8 +352,8 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
     if (active) {
       Cplx<A> *out = a.loop + (int64_t)slot * a.slot_stride;
       const int siteIdx = xmine + pmine * a.volumeCB;
-      if (half == 0) trace_and_store_range<A, 0, 8>(out, full, 2 * a.volumeCB, siteIdx);
-      else trace_and_store_range<A, 8, 16>(out, full, 2 * a.volumeCB, siteIdx);
+      if (half == 0) trace_and_store_range<A, 0, 8>(out, full, 2 * a.volumeCB, siteIdx, a.overwrite != 0);
+      else trace_and_store_range<A, 8, 16>(out, full, 2 * a.volumeCB, siteIdx, a.overwrite != 0);
     }
   }
 }
@@ -459,6 +460,8 @@ int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma,
   a.H = (int)(ev[0].volumeCB / (ev[0].X[dir] * strideMu));
   a.numCols = 2 * ev[0].volumeCB / ev[0].X[dir];
   a.nJT = ev[0].X[dir] / kTileTJ;
+  a.overwrite = (region & MUGIQ_HIP_REGION_OVERWRITE) ? 1 : 0;
+  region &= 0xff;
   for (int k0 = 0; k0 < nK; k0 += kTileMaxSlots) {
     a.nslot = (nK - k0 < kTileMaxSlots) ? nK - k0 : kTileMaxSlots;
     a.loop = static_cast<Cplx<A> *>(loop_d) + (int64_t)k0 * a.slot_stride;

@@ -126,14 +126,14 @@ template <typename F> __device__ inline void accumulate_herm(F diag[4], Cplx<F> 
 }
 
 // trace = sum_{s2} row_value[iG][s2] * resG[s2][column_index[iG][s2]]; loopData[tid + V*iG] += trace (:110-120)
-template <typename F> __device__ inline void trace_and_store(Cplx<F> *loop, const Cplx<F> acc[16], int V, int site) {
+template <typename F> __device__ inline void trace_and_store(Cplx<F> *loop, const Cplx<F> acc[16], int V, int site, bool overwrite = false) {
 #pragma unroll
   for (int iG = 0; iG < 16; iG++) {
     Cplx<F> t{F(0), F(0)};
 #pragma unroll
     for (int s2 = 0; s2 < 4; s2++) add_phase(t, kGammaPhase[iG][s2], acc[s2 * 4 + kGammaColumn[iG][s2]]);
     Cplx<F> *out = loop + (int64_t)V * iG + site;
-    Cplx<F> o = *out;
+    Cplx<F> o = overwrite ? Cplx<F>{F(0), F(0)} : *out;  // overwrite: the slot holds nothing yet (no memset, no read)
     o.re += t.re;
     o.im += t.im;
     *out = o;
@@ -141,14 +141,14 @@ template <typename F> __device__ inline void trace_and_store(Cplx<F> *loop, cons
 }
 
 // the same for the gamma channels [G0, G1) only (the tile kernel splits the 16 channels over the two lane halves)
-template <typename F, int G0, int G1> __device__ inline void trace_and_store_range(Cplx<F> *loop, const Cplx<F> acc[16], int V, int site) {
+template <typename F, int G0, int G1> __device__ inline void trace_and_store_range(Cplx<F> *loop, const Cplx<F> acc[16], int V, int site, bool overwrite = false) {
 #pragma unroll
   for (int iG = G0; iG < G1; iG++) {
     Cplx<F> t{F(0), F(0)};
 #pragma unroll
     for (int s2 = 0; s2 < 4; s2++) add_phase(t, kGammaPhase[iG][s2], acc[s2 * 4 + kGammaColumn[iG][s2]]);
     Cplx<F> *out = loop + (int64_t)V * iG + site;
-    Cplx<F> o = *out;
+    Cplx<F> o = overwrite ? Cplx<F>{F(0), F(0)} : *out;  // overwrite: the slot holds nothing yet (no memset, no read)
     o.re += t.re;
     o.im += t.im;
     *out = o;

@@ -292,12 +292,12 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
     MugiqHipLoop::HaloPost &h = lp->halo[id];
     if ((st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, lp->eVecs.data(), lp->sigma.data(), lp->nEv,
                                                                 links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
-                                                                h.grecv, stop, MUGIQ_HIP_REGION_INTERIOR, lp->stream)))
+                                                                h.grecv, stop, MUGIQ_HIP_REGION_INTERIOR | MUGIQ_HIP_REGION_OVERWRITE, lp->stream)))
       return st;
     MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->stream, h.evHalo, 0));
     return mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, lp->eVecs.data(), lp->sigma.data(), lp->nEv,
                                                              links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim, h.grecv,
-                                                             stop, MUGIQ_HIP_REGION_BOUNDARY, lp->stream);
+                                                             stop, MUGIQ_HIP_REGION_BOUNDARY | MUGIQ_HIP_REGION_OVERWRITE, lp->stream);
   }
   // eigenvector blocks: bounded by the ghost-layer buffers when the dimension is partitioned
   int nb = lp->nEv;
@@ -313,10 +313,12 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
   if (part && (st = ensure_comm_stream(lp))) return st;
   for (int n0 = 0; n0 < lp->nEv; n0 += nb) {
     const int nv = std::min(nb, lp->nEv - n0);
+    // the slots were not zeroed (see mugiq_hip_loop_compute): the first eigenvector block writes them, later ones add
+    const int ow = n0 == 0 ? MUGIQ_HIP_REGION_OVERWRITE : 0;
     if (!part) {
       if ((st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, &lp->eVecs[n0], &lp->sigma[n0], nv,
                                                                   links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
-                                                                  nullptr, 0, MUGIQ_HIP_REGION_ALL, lp->stream)))
+                                                                  nullptr, 0, MUGIQ_HIP_REGION_ALL | ow, lp->stream)))
         return st;
       continue;
     }
@@ -330,12 +332,12 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
     MUGIQ_CHECK_HIP(hipEventRecord(lp->evHalo, lp->commStream));
     if ((st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, &lp->eVecs[n0], &lp->sigma[n0], nv,
                                                                 links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
-                                                                grecv, stop, MUGIQ_HIP_REGION_INTERIOR, lp->stream)))
+                                                                grecv, stop, MUGIQ_HIP_REGION_INTERIOR | ow, lp->stream)))
       return st;
     MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->stream, lp->evHalo, 0));
     if ((st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, &lp->eVecs[n0], &lp->sigma[n0], nv,
                                                                 links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
-                                                                grecv, stop, MUGIQ_HIP_REGION_BOUNDARY, lp->stream)))
+                                                                grecv, stop, MUGIQ_HIP_REGION_BOUNDARY | ow, lp->stream)))
       return st;
   }
   return MUGIQ_HIP_SUCCESS;
@@ -801,7 +803,11 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
       bufByteSize = cb * (size_t)lp->nElemPosLocPerLoop;
     }
     void *slot0 = static_cast<char *>(lp->dataPos_d) + (size_t)bufOffset * cb;
-    MUGIQ_CHECK_HIP(hipMemsetAsync(slot0, 0, bufByteSize, lp->stream));  // :476
+    // cudaMemset :476 -- needed where kernels accumulate into the slots: the ultra-local loop, the BASIC plan, and an OPT
+    // entry that falls back to the step-by-step sequence (length beyond the neighbour).  Reflected entries and the fused
+    // displaced contraction write every site of their slots (MUGIQ_HIP_REGION_OVERWRITE).
+    const bool stepByStep = id >= 0 && lp->commDim[lp->dispDir[id]] && lp->dispStop[id] > lp->localL[lp->dispDir[id]];
+    if (id == -1 || basic || (lp->derivedFrom[id] < 0 && stepByStep)) MUGIQ_CHECK_HIP(hipMemsetAsync(slot0, 0, bufByteSize, lp->stream));
     if (id == -1 && lp->coarseMode && !lp->fineStore) {
       // MG ultra-local loop without materialising the fine vectors
       st = mugiq_hip_prolongate_contract_batched(slot0, lp->loopPrecision, lp->coarseVecs.data(), lp->sigma.data(), lp->nEv,
