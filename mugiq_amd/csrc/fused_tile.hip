@@ -459,7 +459,7 @@ int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma,
   a.strideMu = (int)strideMu;
   a.H = (int)(ev[0].volumeCB / (ev[0].X[dir] * strideMu));
   a.numCols = 2 * ev[0].volumeCB / ev[0].X[dir];
-  a.nJT = ev[0].X[dir] / kTileTJ;
+  a.nJT = dir == 0 ? 1 : ev[0].X[dir] / kTileTJ;  // (the row tile is not cut along x: one "tile", or X0 = 2 would launch nothing)
   a.overwrite = (region & MUGIQ_HIP_REGION_OVERWRITE) ? 1 : 0;
   region &= 0xff;
   for (int k0 = 0; k0 < nK; k0 += kTileMaxSlots) {

@@ -353,6 +353,21 @@ def test_driver_random_shapes_both_fused_plans(hip, seed, monkeypatch):
         assert err < tol and err_mom < tol, (X, prec, order, nev, entry, pad, gpad, tile, err, err_mom)
 
 
+@pytest.mark.parametrize("X", [(2, 2, 4, 8), (2, 8, 8, 8)])
+def test_row_tile_on_the_smallest_x_extent(hip, X):
+    """X0 = 2 (one checkerboard entry per x-row): found by the 2500-seed sweep -- the row tile computed zero tiles along x
+    and launched nothing."""
+    ev, Uo, f, U = _setup(hip, X, 2, 8, 2, 5)
+    sg = sigmas(2)
+    for entry in ("-x:1", "+x:1"):
+        _, s, a, b = orc.parse_disp_entry_string(entry)
+        ref = orc.compute_loop_position_space(ev, sg, orc.LoopComputeParam(s, a, b), Uo, X)
+        loop = hip.Loop_Mugiq(hip.MugiqLoopParam(gauge=U).set_displace_entry_string(entry), f, sg)
+        loop.computeCoarseLoop()
+        assert rel_err(loop.dataPos_d.cpu().numpy(), ref) < 1e-12, entry
+        loop.close()
+
+
 def test_driver_reflects_opposite_sign_entries(hip, monkeypatch):
     """OPT plan: an entry whose direction and lengths were already computed with the opposite sign is derived from it
     (csrc/reflect.hip) instead of going through the eigenvectors again; MUGIQ_HIP_REFLECT=0 and the BASIC plan compute
