@@ -292,6 +292,39 @@ def test_convert_and_project_in_one_call(hip, prec, X, nLoop, coord, tot):
     assert rel_err(out.cpu().numpy(), exp) < (1e-13 if prec == 8 else 5e-6)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MUGIQ_TEST_SEEDS", 16))))
+def test_random_projection_shapes(hip, seed):
+    """Seeded random local lattices, process grids / rank coordinates, momentum lists (unsorted, with repeats) and loop
+    counts through the two projection entry points of the OPT plan."""
+    rng = np.random.default_rng(7000 + seed)
+    X = tuple(int(v) for v in rng.choice([2, 4, 6, 8, 12], size=4))
+    while np.prod(X) > 2048:
+        X = tuple(int(v) for v in rng.choice([2, 4, 6, 8, 12], size=4))
+    grid = [int(v) for v in rng.choice([1, 1, 2, 3], size=3)] + [1]
+    coord = tuple(int(rng.integers(g)) for g in grid)
+    tot = tuple(X[d] * grid[d] for d in range(4))
+    prec = int(rng.choice([8, 4]))
+    nLoop = int(rng.integers(1, 4))
+    nData = 16 * nLoop
+    nmom = int(rng.integers(1, 40))
+    mom = [tuple(int(v) for v in rng.integers(-4, 5, size=3)) for _ in range(nmom)]
+    FTSign = int(rng.choice([-1, 1]))
+    V, locV3 = int(np.prod(X)), X[0] * X[1] * X[2]
+    cdt = _np_c(prec)
+    tdt = torch.complex128 if prec == 8 else torch.complex64
+    pos = (rng.standard_normal(nData * V) + 1j * rng.standard_normal(nData * V)).astype(cdt)
+    mp_ = orc.convert_idx_order_map_gamma(pos.astype(np.complex128), nData, nLoop, 2, V // 2, X)
+    ph = orc.phase_matrix(mom, locV3, FTSign, X, tot, coord, dtype=np.float64 if prec == 8 else np.float32)
+    exp = orc.momentum_projection_local(mp_, ph.astype(np.complex128), X[3], nData, locV3, nmom)
+    tol = 1e-13 if prec == 8 else 1e-5
+    out = torch.zeros(X[3] * nData * nmom, dtype=tdt, device="cuda")
+    hip.convertAndProject(out, torch.from_numpy(pos).cuda(), nData, nLoop, mom, FTSign, X, tot, coord)
+    assert rel_err(out.cpu().numpy(), exp) < tol, ("fused", X, grid, coord, prec, nLoop, nmom)
+    out.zero_()
+    hip.momentumProjectionSeparable(out, torch.from_numpy(mp_.astype(cdt)).cuda(), mom, FTSign, X, tot, X[3], nData, coord)
+    assert rel_err(out.cpu().numpy(), exp) < tol, ("separable", X, grid, coord, prec, nLoop, nmom)
+
+
 def test_full_pipeline_ultralocal_and_displaced_vs_oracle(hip):
     """cfg1-like plumbing on the GPU: 8^4... scaled to 4^3x8, N_ev=4, ultra-local + displaced loops,
     reorder, phases, momentum projection -- operator by operator in the reference's order."""
