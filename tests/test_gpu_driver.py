@@ -291,6 +291,49 @@ def test_driver_mg_coarse_path(hip, calc, entries):
     loop.close()
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MUGIQ_TEST_SEEDS", 8))))
+def test_driver_mg_coarse_path_random(hip, seed):
+    """Seeded random MG set-ups through the driver: aggregate shapes, n_vec (coarse-grid plan for 8/12/16/24/32, the
+    per-eigenvector kernel otherwise), precision incl. mixed, with and without displacement entries."""
+    rng = np.random.default_rng(8100 + seed)
+    X = tuple(int(v) for v in rng.choice([4, 8, 12], size=4))
+    while np.prod(X) > 2048:
+        X = tuple(int(v) for v in rng.choice([4, 8, 12], size=4))
+    bs = tuple(int(rng.choice([b for b in (1, 2, 3, 4, 6) if X[d] % b == 0 and (X[d] // b) % 2 == 0])) for d in range(4))
+    nvec = int(rng.choice([2, 6, 8, 12, 16, 24]))
+    nev = int(rng.integers(1, 6))
+    prec = int(rng.choice([8, 4]))
+    lprec = 8 if (prec == 4 and rng.integers(2)) else prec
+    cdt = np.complex128 if prec == 8 else np.complex64
+    vcb = int(np.prod(X)) // 2
+    Xc = [X[d] // bs[d] for d in range(4)]
+    vcbc = int(np.prod(Xc)) // 2
+    Vn = ((rng.standard_normal((2, vcb, 4, 3, nvec)) + 1j * rng.standard_normal((2, vcb, 4, 3, nvec))) / np.sqrt(12.0 * nvec)).astype(cdt)
+    phis = [(rng.standard_normal((2, vcbc, 2, nvec)) + 1j * rng.standard_normal((2, vcbc, 2, nvec))).astype(cdt) for _ in range(nev)]
+    Uo = orc.extended_gauge_from_global(random_gauge_lex(rng, X), (0, 0, 0, 0), (1, 1, 1, 1), (0, 0, 0, 0)).astype(cdt).astype(np.complex128)
+    sg = sigmas(nev)
+    T = hip.Transfer(X, nvec, bs, 2, prec).set_logical(Vn)
+    cf = [hip.CoarseField(Xc, nvec, prec).set_logical(p) for p in phis]
+    U = hip.GaugeField(X, (0, 0, 0, 0), prec).set_logical(Uo)
+    entries = [None, "+z:1,2;-t:1", "-x:2;+x:2;+y:1,3"][int(rng.integers(3))]
+    prm = hip.MugiqLoopParam(gauge=U, loopPrecision=lprec if lprec != prec else 0)
+    if entries:
+        prm.set_displace_entry_string(entries)
+        _, s, a, b = orc.parse_disp_entry_string(entries)
+        cprm = orc.LoopComputeParam(s, a, b)
+    else:
+        cprm = orc.LoopComputeParam(doNonLocal=False)
+    loop = hip.Loop_Mugiq(prm, cf, sg, transfer=T)
+    loop.computeCoarseLoop()
+    fine = [orc.prolongate(p.astype(np.complex128), Vn.astype(np.complex128), X, bs) for p in phis]
+    if prec == 4 and entries:       # the engine stores the prolonged vectors in fp32 before displacing them
+        fine = [f.astype(np.complex64).astype(np.complex128) for f in fine]
+    ref = orc.compute_loop_position_space(fine, np.float32(sg).astype(np.float64) if prec == 4 else sg, cprm, Uo, X)
+    tol = 1e-12 if prec == 8 else 2e-5
+    assert rel_err(loop.dataPos_d.cpu().numpy(), ref) < tol, (X, bs, nvec, nev, prec, lprec, entries)
+    loop.close()
+
+
 @pytest.mark.parametrize("X", [(4, 8, 4, 8), (8, 4, 4, 8), (6, 4, 12, 4), (16, 4, 4, 4)])
 @pytest.mark.parametrize("tile", ["0", "1"])
 def test_fused_plans_agree_tiled_and_streaming(hip, tile, X, monkeypatch):
