@@ -133,11 +133,15 @@ static int scratch_alloc(MugiqHipLoop *lp, void **p, size_t bytes, bool zero) {
 }
 
 // A FLOAT2, pad-0 scratch field with the eigenvectors' geometry (+ room for both depth-1 ghost zones of `dim`).
-static int make_scratch_field(MugiqHipLoop *lp, MugiqHipSpinorField *f, int order, bool zero = false) {
+// (likeEvecs: keep the eigenvectors' own stride / pad, as Displace's auxDispVec does -- lib/displace.cpp:32-37 creates it
+// from the eigenvectors' parameters -- so that it can stand in for an eigenvector in the batched kernels)
+static int make_scratch_field(MugiqHipLoop *lp, MugiqHipSpinorField *f, int order, bool zero = false, bool likeEvecs = false) {
   *f = lp->eVecs[0];
   f->field_order = order;
-  f->stride = lp->volumeCB;
-  f->parity_offset = (int64_t)12 * lp->volumeCB;
+  if (!likeEvecs) {
+    f->stride = lp->volumeCB;
+    f->parity_offset = (int64_t)12 * lp->volumeCB;
+  }
   for (int d = 0; d < 4; d++) f->ghost[d][0] = f->ghost[d][1] = nullptr;
   void *p = nullptr;
   int st = scratch_alloc(lp, &p, (size_t)2 * f->parity_offset * lp->cplxBytes(), zero);
@@ -166,7 +170,7 @@ static int entry_basic(MugiqHipLoop *lp, int id, void *slot0) {
   MugiqHipSpinorField aux[2];
   int st;
   for (int i = 0; i < 2; i++)
-    if ((st = make_scratch_field(lp, &aux[i], lp->order))) return st;  // fully written by every displacement
+    if ((st = make_scratch_field(lp, &aux[i], lp->order, false, true))) return st;  // fully written by every displacement
   void *send_d = nullptr, *recv_d = nullptr;
   if (part) {
     const size_t fb = (size_t)24 * (lp->volumeCB / lp->localL[dir]) * lp->cplxBytes();

@@ -394,6 +394,15 @@ def test_driver_random_shapes_both_fused_plans(hip, seed, monkeypatch):
         err_mom = rel_err(loop.dataMom_bcast, ref_mom)
         loop.close()
         assert err < tol and err_mom < tol, (X, prec, order, nev, entry, pad, gpad, tile, err, err_mom)
+    if os.environ.get("MUGIQ_TEST_BASIC") or seed % 8 == 0:       # the reference's launch sequence on a subset (all with MUGIQ_TEST_BASIC=1)
+        prm = hip.MugiqLoopParam(gauge=U, FTSign=FTSign, doMomProj=True, momMatrix=[list(m) for m in moms], Nmom=len(moms),
+                                 calcType=hip.LOOP_CALC_TYPE_BASIC_KERNEL)
+        loop = hip.Loop_Mugiq(prm.set_displace_entry_string(entry), f, sg)
+        loop.computeCoarseLoop()
+        err = rel_err(loop.dataPos_d.cpu().numpy(), ref)
+        err_mom = rel_err(loop.dataMom_bcast, ref_mom)
+        loop.close()
+        assert err < tol and err_mom < tol, (X, prec, order, nev, entry, pad, gpad, "basic", err, err_mom)
 
 
 @pytest.mark.parametrize("X", [(2, 2, 4, 8), (2, 8, 8, 8)])
