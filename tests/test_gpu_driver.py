@@ -405,6 +405,47 @@ def test_driver_random_shapes_both_fused_plans(hip, seed, monkeypatch):
         assert err < tol and err_mom < tol, (X, prec, order, nev, entry, pad, gpad, "basic", err, err_mom)
 
 
+def test_full_size_reflected_entries_agree_with_computed_ones(hip, monkeypatch):
+    """BASELINE.json configs[2] per-GPU lattice (48.48.24.24), few eigenvectors: the OPT plan with reflected entries, without
+    them, and with the streaming kernel give the same 25 loop slots (a size-independent property; the oracle is too
+    slow at this size)."""
+    X = (48, 48, 24, 24)
+    V = int(np.prod(X))
+    nev = 3
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    f = []
+    for n in range(nev):
+        sp = hip.SpinorField(X, 8, 2)
+        sp.data.copy_(torch.complex(torch.randn(sp.data.numel(), dtype=torch.float64, device="cuda", generator=gen),
+                                    torch.randn(sp.data.numel(), dtype=torch.float64, device="cuda", generator=gen)) / np.sqrt(24.0 * V))
+        f.append(sp)
+    vcb = V // 2
+    m = torch.complex(torch.randn(8 * vcb, 3, 3, dtype=torch.float64, device="cuda", generator=gen),
+                      torch.randn(8 * vcb, 3, 3, dtype=torch.float64, device="cuda", generator=gen))
+    r0 = m[:, 0] / torch.linalg.vector_norm(m[:, 0], dim=-1, keepdim=True)
+    r1 = m[:, 1] - (r0.conj() * m[:, 1]).sum(-1, keepdim=True) * r0
+    r1 = r1 / torch.linalg.vector_norm(r1, dim=-1, keepdim=True)
+    r2 = torch.linalg.cross(r0.conj(), r1.conj())
+    U = hip.GaugeField(X, (0, 0, 0, 0), 8)
+    U.data.copy_(torch.stack([r0, r1, r2], dim=1).reshape(4, 2, vcb, 9).permute(1, 0, 3, 2).contiguous().reshape(-1))
+    entry = "+x:1,3;-x:1,3;+y:1,3;-y:1,3;+z:1,3;-z:1,3;+t:1,3;-t:1,3"
+    sg = sigmas(nev)
+    res = {}
+    for mode, env in (("reflect", {}), ("direct", {"MUGIQ_HIP_REFLECT": "0"}), ("streaming", {"MUGIQ_HIP_REFLECT": "0", "MUGIQ_HIP_FUSED_TILE": "0"})):
+        for k in ("MUGIQ_HIP_REFLECT", "MUGIQ_HIP_FUSED_TILE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        loop = hip.Loop_Mugiq(hip.MugiqLoopParam(gauge=U).set_displace_entry_string(entry), f, sg)
+        loop.computeCoarseLoop()
+        assert sum(loop.derivedFrom(i) >= 0 for i in range(8)) == (4 if mode == "reflect" else 0)
+        res[mode] = loop.dataPos_d.clone()
+        loop.close()
+    scale = float(res["direct"].abs().max())
+    assert float((res["reflect"] - res["direct"]).abs().max()) < 1e-12 * scale
+    assert float((res["streaming"] - res["direct"]).abs().max()) < 1e-12 * scale
+
+
 @pytest.mark.parametrize("X", [(2, 2, 4, 8), (2, 8, 8, 8)])
 def test_row_tile_on_the_smallest_x_extent(hip, X):
     """X0 = 2 (one checkerboard entry per x-row): found by the 2500-seed sweep -- the row tile computed zero tiles along x
