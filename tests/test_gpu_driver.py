@@ -157,11 +157,12 @@ def test_two_rank_driver_interior_boundary_tiles(grid, G, prec, order):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MUGIQ_TEST_MP_SEEDS", 4))))
 def test_two_rank_driver_random_entries(seed):
     """Seeded random entry lists (both signs, lengths 1..5 against a local extent of 4: reflected entries with and without
-    halo, lengths past the neighbour) on a randomly chosen partitioned axis, OPT plan."""
+    halo, lengths past the neighbour) on a randomly chosen partitioned axis; OPT plan, every third case BASIC."""
     axis = (seed * 7 + 3) % 4
     grid = tuple(2 if d == axis else 1 for d in range(4))
     prec, order = [(8, 2), (4, 4), (8, 4), (4, 2)][seed % 4]
-    mp.spawn(mp_workers.gpu_worker, args=(2, free_port(), grid, prec, order, 1, (8, 8, 8, 8), 9000 + seed), nprocs=2, join=True)
+    calc = 2 if seed % 3 == 2 else 1                                  # every third case through the BASIC plan
+    mp.spawn(mp_workers.gpu_worker, args=(2, free_port(), grid, prec, order, calc, (8, 8, 8, 8), 9000 + seed), nprocs=2, join=True)
 
 
 def test_four_rank_driver_z_and_t_partitioned_on_one_gpu():
