@@ -98,6 +98,16 @@ int mugiq_hip_version(void);
 const char *mugiq_hip_last_error(void);
 /* number of visible HIP devices (0 if none); does not initialise a context */
 int mugiq_hip_device_count(void);
+/* Streams and re-entrancy.  Every entry point that launches kernels takes the HIP stream they run on.  The small device
+ * tables a call uploads for its kernels (eigenvector pointer lists, 1/sigma, momenta) and the workspaces the library
+ * allocates when the caller passes none are kept PER (device, stream): calls issued on different streams -- from one
+ * thread or several, through free operators or through different MugiqHipLoop objects -- are independent; calls on
+ * one stream are ordered by the stream.  (The reference's wrappers are single-stream and not re-entrant: per-call
+ * cudaMalloc + cudaDeviceSynchronize, lib/contract_wrappers.cu:93-114.)  Two host threads must not issue calls on the
+ * SAME stream at the same time.  mugiq_hip_release_stream drains `stream` and frees what the library holds for it; call
+ * it before destroying a stream that was passed to this library (optional: the buffers are small and are reused if the
+ * handle value comes back). */
+int mugiq_hip_release_stream(void *stream);
 
 /* Roofline calibration (measurement aid, not part of the reference): stream-read `bytes` of buf_d once with 16-B
  * loads per lane (plain or non-temporal) and write nothing.  Time it with events to get the achievable HBM read
@@ -410,6 +420,32 @@ int mugiq_hip_loop_get_entry(const MugiqHipLoop *loop, int id, int out6[6]);
 /* After mugiq_hip_loop_compute: the entry that entry `id` was reflected from (see mugiq_hip_reflect_displaced_loop), or
  * -1 if it was computed from the eigenvectors; -2 for a bad handle / index. */
 int mugiq_hip_loop_entry_derived_from(const MugiqHipLoop *loop, int id);
+/* Phase timing of a compute (measurement aid; off by default).  When switched on, mugiq_hip_loop_compute brackets each
+ * phase with a pair of HIP events on the stream the phase runs on and, after its final synchronisation, reports the
+ * device time between them.  Phases of different streams overlap in time (that is the point of the halo stream). */
+#define MUGIQ_HIP_PHASE_ULTRA_LOCAL 0          /* the ultra-local slot (lib/loop_mugiq.cpp:501-502 over all eigenvectors) */
+#define MUGIQ_HIP_PHASE_ENTRY_FUSED 1          /* a displacement entry computed from the eigenvectors, one domain along its axis */
+#define MUGIQ_HIP_PHASE_ENTRY_REFLECTED 2      /* an entry derived from its opposite-sign partner */
+#define MUGIQ_HIP_PHASE_ENTRY_STEPWISE 3       /* an entry through the step-by-step sequence (BASIC plan, or length > local extent) */
+#define MUGIQ_HIP_PHASE_MOMENTUM_PROJECTION 4  /* reorder + Fourier sums on the device */
+#define MUGIQ_HIP_PHASE_HALO_TRANSFER 5        /* eigenvector halo on the halo stream; bytes = what this rank sends */
+#define MUGIQ_HIP_PHASE_ENTRY_INTERIOR 6       /* partitioned entry: tiles that need no ghost layers */
+#define MUGIQ_HIP_PHASE_ENTRY_BOUNDARY 7       /* partitioned entry: tiles that read the ghost layers */
+#define MUGIQ_HIP_PHASE_PROLONGATION 8         /* MG path: coarse -> fine for all eigenvectors */
+#define MUGIQ_HIP_PHASE_HALO_PREPARE 9         /* path-link fields + packing of the face layers of one entry; bytes packed */
+#define MUGIQ_HIP_PHASE_HALO_WAIT 10           /* compute stream idle until the halo has landed (what the overlap did not hide) */
+#define MUGIQ_HIP_PHASE_MOMENTUM_COPY 11       /* dataMom_d -> pinned host */
+#define MUGIQ_HIP_PHASE_MOMENTUM_REDUCE 12     /* host: reduce over space ranks, gather over time ranks, broadcast (wall time) */
+#define MUGIQ_HIP_PHASE_TOTAL_WALL 13          /* host wall time of the whole mugiq_hip_loop_compute call */
+typedef struct MugiqHipLoopPhase_s {
+  int kind;     /* MUGIQ_HIP_PHASE_* */
+  int entry;    /* displacement entry the phase belongs to, or -1 */
+  double ms;    /* device time between the bracketing events (host wall time for kinds 12, 13) */
+  double bytes; /* halo / copy phases: bytes moved by this rank; else 0 */
+} MugiqHipLoopPhase;
+int mugiq_hip_loop_set_profiling(MugiqHipLoop *loop, int on);
+/* phases of the last compute, in issue order; returns their number (may exceed max_phases; out may be NULL to ask) */
+int mugiq_hip_loop_get_phases(const MugiqHipLoop *loop, MugiqHipLoopPhase *out, int max_phases);
 /* dataPos_d: [nLoop][16][V even-odd] complex, device.  dataPos (host) is copied on first request
  * (the reference copies it unconditionally at lib/loop_mugiq.cpp:512). */
 const void *mugiq_hip_loop_data_pos_d(const MugiqHipLoop *loop);

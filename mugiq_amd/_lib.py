@@ -59,6 +59,7 @@ SIGNATURES = {
     "mugiq_hip_version": (ctypes.c_int, []),
     "mugiq_hip_last_error": (ctypes.c_char_p, []),
     "mugiq_hip_device_count": (ctypes.c_int, []),
+    "mugiq_hip_release_stream": (ctypes.c_int, [_VP]),
     "mugiq_hip_probe_read_bandwidth": (ctypes.c_int, [_VP, ctypes.c_size_t, ctypes.c_int, _VP]),
     "mugiq_hip_copy_gamma_coeff_to_symbol": (ctypes.c_int, [ctypes.c_int]),
     "mugiq_hip_copy_gamma_map_to_symbol": (ctypes.c_int, [ctypes.c_int]),
@@ -111,6 +112,8 @@ SIGNATURES = {
                                                     ctypes.c_int, _VP, _VP]),
     "mugiq_hip_loop_compute": (ctypes.c_int, [_VP]),
     "mugiq_hip_loop_get_info": (ctypes.c_int, [_VP, _VP]),
+    "mugiq_hip_loop_set_profiling": (ctypes.c_int, [_VP, ctypes.c_int]),
+    "mugiq_hip_loop_get_phases": (ctypes.c_int, [_VP, _VP, ctypes.c_int]),
     "mugiq_hip_loop_get_entry": (ctypes.c_int, [_VP, ctypes.c_int, _I4]),
     "mugiq_hip_loop_entry_derived_from": (ctypes.c_int, [_VP, ctypes.c_int]),
     "mugiq_hip_loop_data_pos_d": (_VP, [_VP]),

@@ -57,6 +57,10 @@ class GridComm:
         self.is_time_process = self.coord[:3] == (0, 0, 0)
         self._cb = None
         self._group = None            # deferred (send, recv, staged recv target, dst, src) while a group is open
+        # A grid of extent 1 along `dim` makes a rank its own neighbour; the driver never exchanges along such an axis, so
+        # sendrecv serves it with a local copy.  loopback_through_transport = True sends that message through the transport
+        # as well (a send to self inside one batch): it lets ONE rank exercise the real isend/irecv path of the backend.
+        self.loopback_through_transport = False
 
     # ---- topology (QUDA's comm_rank_from_coords: x slowest, t fastest) --------------------------------------
     def coords_of(self, rank):
@@ -87,10 +91,11 @@ class GridComm:
         stage = self.backend == "gloo" and send.is_cuda
         s = send.cpu() if stage else send
         r = torch.empty_like(recv, device="cpu") if stage else recv
-        if self._group is not None and dst != self.rank:
+        local = dst == self.rank and not self.loopback_through_transport
+        if self._group is not None and not local:
             self._group.append((s, r, recv if stage else None, dst, src))     # issued together at group_end
             return
-        if dst == self.rank:                      # grid of 1 in this dim (not called by the driver) -> periodic copy
+        if local:                                 # grid of 1 in this dim (not called by the driver) -> periodic copy
             r.copy_(s)
         else:
             ops = [dist.P2POp(dist.isend, s, dst), dist.P2POp(dist.irecv, r, src)]

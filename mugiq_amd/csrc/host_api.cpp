@@ -1,5 +1,6 @@
 // Host-side plumbing of libmugiq_hip.so: error reporting, gamma tables, descriptor validation.
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 
@@ -19,51 +20,96 @@ int set_error(int status, const char *fmt, ...) {
   return status;
 }
 
-int device_scratch(void **ptr, size_t bytes) {
-  static std::mutex mtx;
-  static void *buf[16] = {nullptr};
-  static size_t cap[16] = {0};
-  std::lock_guard<std::mutex> lock(mtx);
-  int dev = 0;
-  MUGIQ_CHECK_HIP(hipGetDevice(&dev));
-  MUGIQ_REQUIRE(dev >= 0 && dev < 16, "device ordinal %d out of range", dev);
-  if (bytes > cap[dev]) {
-    if (buf[dev]) {
-      MUGIQ_CHECK_HIP(hipDeviceSynchronize());
-      MUGIQ_CHECK_HIP(hipFree(buf[dev]));
-      buf[dev] = nullptr;
-      cap[dev] = 0;
-    }
-    size_t want = bytes < (1u << 16) ? (1u << 16) : bytes * 2;
-    MUGIQ_CHECK_HIP(hipMalloc(&buf[dev], want));
-    cap[dev] = want;
+// ---- per-stream scratch ---------------------------------------------------------------------------------------------
+// Every C-ABI entry takes the stream its kernels run on; the small tables those kernels read (eigenvector pointer lists,
+// 1/sigma, momenta, phases) and the workspaces the library allocates for the caller live in an arena keyed by
+// (device, stream).  Calls on ONE stream are ordered by the stream itself (the table upload of call n+1 is enqueued behind
+// the kernel of call n), calls on different streams, threads or Loop objects never share a buffer.
+namespace {
+struct StreamArena {
+  void *tab = nullptr, *ws = nullptr, *pinned = nullptr;
+  size_t tabCap = 0, wsCap = 0, pinnedCap = 0;
+  hipEvent_t staged = nullptr;  // the last table has left the pinned staging buffer
+};
+std::mutex g_arenaMtx;
+std::map<std::pair<int, hipStream_t>, StreamArena> g_arenas;
+
+// grow-only buffer of an arena; the old buffer may still be read by kernels of THIS stream only, so that stream is drained
+int arena_reserve(void **buf, size_t *cap, size_t bytes, size_t floor, hipStream_t stream) {
+  if (bytes <= *cap) return MUGIQ_HIP_SUCCESS;
+  if (*buf) {
+    MUGIQ_CHECK_HIP(hipStreamSynchronize(stream));
+    MUGIQ_CHECK_HIP(hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
   }
-  *ptr = buf[dev];
+  const size_t want = bytes < floor ? floor : bytes + bytes / 2;
+  MUGIQ_CHECK_HIP(hipMalloc(buf, want));
+  *cap = want;
+  return MUGIQ_HIP_SUCCESS;
+}
+int current_device(int *dev) {
+  MUGIQ_CHECK_HIP(hipGetDevice(dev));
+  return MUGIQ_HIP_SUCCESS;
+}
+}  // namespace
+
+int stream_scratch(void **ptr, size_t bytes, hipStream_t stream) {
+  int dev = 0, st = current_device(&dev);
+  if (st) return st;
+  std::lock_guard<std::mutex> lock(g_arenaMtx);
+  StreamArena &a = g_arenas[{dev, stream}];
+  if ((st = arena_reserve(&a.tab, &a.tabCap, bytes, 1u << 16, stream))) return st;
+  *ptr = a.tab;
   return MUGIQ_HIP_SUCCESS;
 }
 
-int upload_table(void **dev, const void *host, size_t bytes, hipStream_t stream) {
-  static std::mutex mtx;
-  static void *pinned[16] = {nullptr};
-  static size_t cap[16] = {0};
-  static hipEvent_t done[16] = {nullptr};
-  int st = device_scratch(dev, bytes);
+int stream_workspace(void **ptr, size_t bytes, hipStream_t stream) {
+  int dev = 0, st = current_device(&dev);
   if (st) return st;
-  std::lock_guard<std::mutex> lock(mtx);
-  int d = 0;
-  MUGIQ_CHECK_HIP(hipGetDevice(&d));
-  if (!done[d]) MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&done[d], hipEventDisableTiming));
-  else MUGIQ_CHECK_HIP(hipEventSynchronize(done[d]));  // previous table has left the staging buffer
-  if (bytes > cap[d]) {
-    if (pinned[d]) MUGIQ_CHECK_HIP(hipHostFree(pinned[d]));
-    pinned[d] = nullptr;
-    size_t want = bytes < (1u << 16) ? (1u << 16) : bytes * 2;
-    MUGIQ_CHECK_HIP(hipHostMalloc(&pinned[d], want, hipHostMallocDefault));
-    cap[d] = want;
+  std::lock_guard<std::mutex> lock(g_arenaMtx);
+  StreamArena &a = g_arenas[{dev, stream}];
+  if ((st = arena_reserve(&a.ws, &a.wsCap, bytes, 256, stream))) return st;
+  *ptr = a.ws;
+  return MUGIQ_HIP_SUCCESS;
+}
+
+int upload_table(void **dev_out, const void *host, size_t bytes, hipStream_t stream) {
+  int dev = 0, st = current_device(&dev);
+  if (st) return st;
+  std::lock_guard<std::mutex> lock(g_arenaMtx);
+  StreamArena &a = g_arenas[{dev, stream}];
+  if ((st = arena_reserve(&a.tab, &a.tabCap, bytes, 1u << 16, stream))) return st;
+  if (!a.staged) MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&a.staged, hipEventDisableTiming));
+  else MUGIQ_CHECK_HIP(hipEventSynchronize(a.staged));  // previous table has left the staging buffer
+  if (bytes > a.pinnedCap) {
+    if (a.pinned) MUGIQ_CHECK_HIP(hipHostFree(a.pinned));
+    a.pinned = nullptr;
+    a.pinnedCap = 0;
+    const size_t want = bytes < (1u << 16) ? (1u << 16) : bytes * 2;
+    MUGIQ_CHECK_HIP(hipHostMalloc(&a.pinned, want, hipHostMallocDefault));
+    a.pinnedCap = want;
   }
-  memcpy(pinned[d], host, bytes);
-  MUGIQ_CHECK_HIP(hipMemcpyAsync(*dev, pinned[d], bytes, hipMemcpyHostToDevice, stream));
-  MUGIQ_CHECK_HIP(hipEventRecord(done[d], stream));
+  memcpy(a.pinned, host, bytes);
+  MUGIQ_CHECK_HIP(hipMemcpyAsync(a.tab, a.pinned, bytes, hipMemcpyHostToDevice, stream));
+  MUGIQ_CHECK_HIP(hipEventRecord(a.staged, stream));
+  *dev_out = a.tab;
+  return MUGIQ_HIP_SUCCESS;
+}
+
+int release_stream_scratch(hipStream_t stream) {
+  int dev = 0, st = current_device(&dev);
+  if (st) return st;
+  std::lock_guard<std::mutex> lock(g_arenaMtx);
+  auto it = g_arenas.find({dev, stream});
+  if (it == g_arenas.end()) return MUGIQ_HIP_SUCCESS;
+  MUGIQ_CHECK_HIP(hipStreamSynchronize(stream));
+  StreamArena &a = it->second;
+  if (a.tab) (void)hipFree(a.tab);
+  if (a.ws) (void)hipFree(a.ws);
+  if (a.pinned) (void)hipHostFree(a.pinned);
+  if (a.staged) (void)hipEventDestroy(a.staged);
+  g_arenas.erase(it);
   return MUGIQ_HIP_SUCCESS;
 }
 
@@ -106,6 +152,8 @@ extern "C" {
 int mugiq_hip_version(void) { return MUGIQ_HIP_VERSION; }
 
 const char *mugiq_hip_last_error(void) { return g_last_error.c_str(); }
+
+int mugiq_hip_release_stream(void *stream) { return release_stream_scratch(static_cast<hipStream_t>(stream)); }
 
 int mugiq_hip_device_count(void) {
   int n = 0;

@@ -24,12 +24,16 @@ int set_error(int status, const char *fmt, ...);
     if (!(cond)) return ::mugiq::set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, __VA_ARGS__);        \
   } while (0)
 
-// Small device scratch for per-call tables (pointer lists, sigmas); grows on demand, per process.
-int device_scratch(void **ptr, size_t bytes);
-// Copy a small host table into the device scratch on `stream` (through a pinned staging buffer, so the
-// caller's memory may be released on return).  Tables of successive calls reuse the same scratch: calls
-// must be issued on one stream at a time per device (the reference's wrappers are not re-entrant either).
+// Per-(device, stream) scratch (host_api.cpp).  Small tables (pointer lists, 1/sigma, momenta) go through
+// upload_table: a pinned staging copy, then an H2D copy ordered on `stream`, so the caller's memory may be released
+// on return.  Successive calls on one stream reuse the same buffer -- safe because the stream orders the next upload
+// behind the previous kernel; calls on different streams (or threads, or Loop objects) never share one.
+// stream_scratch returns the table buffer itself (at least `bytes` large; the next upload_table of at most that size
+// on the same stream lands at the same address); stream_workspace is a second, independent buffer of the same arena.
+int stream_scratch(void **ptr, size_t bytes, hipStream_t stream);
+int stream_workspace(void **ptr, size_t bytes, hipStream_t stream);
 int upload_table(void **dev, const void *host, size_t bytes, hipStream_t stream);
+int release_stream_scratch(hipStream_t stream);
 int fill_identity_links(const MugiqHipSpinorField *f, hipStream_t stream);  // displace.hip
 
 // ---- address spaces ---------------------------------------------------------------------------------------------

@@ -9,6 +9,7 @@
 // of swapAuxDispVec (lib/displace.cpp:47-59), the per-launch cudaMalloc/cudaMemcpy/cudaFree/cudaDeviceSynchronize
 // (lib/contract_wrappers.cu:93-114), and the exchange of all four faces in both directions per step.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -98,6 +99,17 @@ struct MugiqHipLoop_s {
   std::vector<HaloPost> halo;   // per displacement entry
   std::vector<void *> held;     // pool buffers held until the end of the compute
 
+  // ---- optional phase timing (mugiq_hip_loop_set_profiling): device time between two events bracketing each phase
+  struct Phase {
+    int kind, entry;
+    double bytes, ms;
+    int e0, e1;  // indices into `events`, -1 = host-timed (ms already set)
+  };
+  bool profiling = false;
+  std::vector<Phase> phases;
+  std::vector<hipEvent_t> events;
+  size_t eventsUsed = 0;
+
   size_t cplxBytes() const { return 2 * (size_t)precision; }      // eigenvector / link storage
   size_t loopBytes() const { return 2 * (size_t)loopPrecision; }  // loop buffers, phases, momentum projection
 };
@@ -112,6 +124,39 @@ static int dev_alloc(MugiqHipLoop *lp, void **p, size_t bytes, bool zero) {
   MUGIQ_CHECK_HIP(hipMalloc(p, bytes ? bytes : 16));
   if (zero) MUGIQ_CHECK_HIP(hipMemsetAsync(*p, 0, bytes, lp->stream));
   return MUGIQ_HIP_SUCCESS;
+}
+
+// ---- phase timing ----------------------------------------------------------------------------------------------
+static int timing_event(MugiqHipLoop *lp, hipStream_t s) {
+  if (lp->eventsUsed == lp->events.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return -1;
+    lp->events.push_back(e);
+  }
+  const int i = (int)lp->eventsUsed++;
+  if (hipEventRecord(lp->events[i], s) != hipSuccess) return -1;
+  return i;
+}
+// opens a phase on stream `s`; returns its index (or -1 when profiling is off)
+static int phase_begin(MugiqHipLoop *lp, int kind, int entry, hipStream_t s, double bytes = 0) {
+  if (!lp->profiling) return -1;
+  lp->phases.push_back({kind, entry, bytes, 0.0, timing_event(lp, s), -1});
+  return (int)lp->phases.size() - 1;
+}
+static void phase_end(MugiqHipLoop *lp, int idx, hipStream_t s) {
+  if (idx >= 0) lp->phases[idx].e1 = timing_event(lp, s);
+}
+static void phase_host(MugiqHipLoop *lp, int kind, double ms, double bytes = 0) {
+  if (lp->profiling) lp->phases.push_back({kind, -1, bytes, ms, -1, -1});
+}
+// after the streams have been synchronised: events -> milliseconds
+static void phases_resolve(MugiqHipLoop *lp) {
+  for (auto &ph : lp->phases)
+    if (ph.e0 >= 0 && ph.e1 >= 0) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, lp->events[ph.e0], lp->events[ph.e1]) == hipSuccess) ph.ms = ms;
+      ph.e0 = ph.e1 = -1;
+    }
 }
 
 // scratch from the loop's pool (best fit among the free buffers, else a new allocation); returned by free_scratch
@@ -245,6 +290,7 @@ static int prepare_halo(MugiqHipLoop *lp, int id, size_t *budget) {
     MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&h.evPacked, hipEventDisableTiming));
     MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&h.evHalo, hipEventDisableTiming));
   }
+  const int ph = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_PREPARE, id, lp->stream, (double)bytes);
   if ((st = build_path_links(lp, id, h.E))) return st;
   if ((st = scratch_alloc(lp, &h.gsend, bytes, false))) return st;
   if ((st = scratch_alloc(lp, &h.grecv, bytes, false))) return st;
@@ -255,6 +301,7 @@ static int prepare_halo(MugiqHipLoop *lp, int id, size_t *budget) {
   const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
   if ((st = mugiq_hip_pack_face_layers(h.gsend, lp->eVecs.data(), lp->nEv, dir, high, stop, lp->stream))) return st;
   MUGIQ_CHECK_HIP(hipEventRecord(h.evPacked, lp->stream));
+  phase_end(lp, ph, lp->stream);
   h.posted = true;
   return MUGIQ_HIP_SUCCESS;
 }
@@ -294,14 +341,21 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
     // the halo of all eigenvectors was posted at the start of the compute: interior tiles, then (once it has landed) the
     // boundary tiles
     MugiqHipLoop::HaloPost &h = lp->halo[id];
+    int ph = phase_begin(lp, MUGIQ_HIP_PHASE_ENTRY_INTERIOR, id, lp->stream);
     if ((st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, lp->eVecs.data(), lp->sigma.data(), lp->nEv,
                                                                 links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
                                                                 h.grecv, stop, MUGIQ_HIP_REGION_INTERIOR | MUGIQ_HIP_REGION_OVERWRITE, lp->stream)))
       return st;
+    phase_end(lp, ph, lp->stream);
+    ph = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_WAIT, id, lp->stream);  // idle time of the compute stream: what the overlap did not hide
     MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->stream, h.evHalo, 0));
-    return mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, lp->eVecs.data(), lp->sigma.data(), lp->nEv,
-                                                             links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim, h.grecv,
-                                                             stop, MUGIQ_HIP_REGION_BOUNDARY | MUGIQ_HIP_REGION_OVERWRITE, lp->stream);
+    phase_end(lp, ph, lp->stream);
+    ph = phase_begin(lp, MUGIQ_HIP_PHASE_ENTRY_BOUNDARY, id, lp->stream);
+    st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, lp->eVecs.data(), lp->sigma.data(), lp->nEv,
+                                                           links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim, h.grecv,
+                                                           stop, MUGIQ_HIP_REGION_BOUNDARY | MUGIQ_HIP_REGION_OVERWRITE, lp->stream);
+    phase_end(lp, ph, lp->stream);
+    return st;
   }
   // eigenvector blocks: bounded by the ghost-layer buffers when the dimension is partitioned
   int nb = lp->nEv;
@@ -331,18 +385,26 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
     if ((st = mugiq_hip_pack_face_layers(gsend, &lp->eVecs[n0], nv, dir, high, stop, lp->stream))) return st;
     MUGIQ_CHECK_HIP(hipEventRecord(lp->evPacked, lp->stream));
     MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, lp->evPacked, 0));
+    int ph = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_TRANSFER, id, lp->commStream, (double)(perVec * nv));
     st = lp->comm.sendrecv(lp->comm.ctx, gsend, grecv, perVec * nv, dir, high ? +1 : -1, lp->commStream);
     if (st) return set_error(MUGIQ_HIP_ERROR_HIP, "halo sendrecv callback failed with status %d", st);
+    phase_end(lp, ph, lp->commStream);
     MUGIQ_CHECK_HIP(hipEventRecord(lp->evHalo, lp->commStream));
+    ph = phase_begin(lp, MUGIQ_HIP_PHASE_ENTRY_INTERIOR, id, lp->stream);
     if ((st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, &lp->eVecs[n0], &lp->sigma[n0], nv,
                                                                 links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
                                                                 grecv, stop, MUGIQ_HIP_REGION_INTERIOR | ow, lp->stream)))
       return st;
+    phase_end(lp, ph, lp->stream);
+    ph = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_WAIT, id, lp->stream);
     MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->stream, lp->evHalo, 0));
+    phase_end(lp, ph, lp->stream);
+    ph = phase_begin(lp, MUGIQ_HIP_PHASE_ENTRY_BOUNDARY, id, lp->stream);
     if ((st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, &lp->eVecs[n0], &lp->sigma[n0], nv,
                                                                 links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
                                                                 grecv, stop, MUGIQ_HIP_REGION_BOUNDARY | ow, lp->stream)))
       return st;
+    phase_end(lp, ph, lp->stream);
   }
   return MUGIQ_HIP_SUCCESS;
 }
@@ -410,6 +472,7 @@ static void destroy_pool(MugiqHipLoop *lp) {
 static int momentum_projection(MugiqHipLoop *lp) {
   if (lp->momProjDone) return set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "performMomentumProjection: Not supposed to be called more than once!!");
   int st;
+  const int phDev = phase_begin(lp, MUGIQ_HIP_PHASE_MOMENTUM_PROJECTION, -1, lp->stream);
   if (lp->calcType == MUGIQ_HIP_LOOP_CALC_TYPE_BASIC_KERNEL) {
     // the reference's sequence: reorder (:343-344), then one dense product with the phase matrix of createPhaseMatrixGPU (:363-378)
     if (!lp->dataPosMP_d && (st = dev_alloc(lp, &lp->dataPosMP_d, (size_t)lp->nElemPosLoc * lp->loopBytes(), true))) return st;
@@ -444,8 +507,12 @@ static int momentum_projection(MugiqHipLoop *lp) {
     }
   }
   const size_t locBytes = (size_t)lp->nElemMomLoc * lp->loopBytes();
+  phase_end(lp, phDev, lp->stream);
+  const int phCopy = phase_begin(lp, MUGIQ_HIP_PHASE_MOMENTUM_COPY, -1, lp->stream, (double)locBytes);
   MUGIQ_CHECK_HIP(hipMemcpyAsync(lp->dataMom_h, lp->dataMom_d, locBytes, hipMemcpyDeviceToHost, lp->stream));  // :386
+  phase_end(lp, phCopy, lp->stream);
   MUGIQ_CHECK_HIP(hipStreamSynchronize(lp->stream));
+  const auto tRed0 = std::chrono::steady_clock::now();
   if (lp->haveComm && lp->comm.size > 1) {
     const size_t nReal = 2 * (size_t)lp->nElemMomLoc;
     if ((st = lp->comm.reduce_space(lp->comm.ctx, lp->dataMom_h, lp->dataMom, nReal, lp->loopPrecision)))  // :406
@@ -455,6 +522,8 @@ static int momentum_projection(MugiqHipLoop *lp) {
     if ((st = lp->comm.bcast(lp->comm.ctx, lp->dataMom_bcast, 2 * (size_t)lp->nElemMomTot, lp->loopPrecision)))  // :424
       return set_error(MUGIQ_HIP_ERROR_HIP, "bcast callback failed with status %d", st);
   }  // (one process: dataMom and dataMom_bcast alias dataMom_h)
+  phase_host(lp, MUGIQ_HIP_PHASE_MOMENTUM_REDUCE, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tRed0).count(),
+             2.0 * (double)lp->nElemMomLoc * lp->loopPrecision);
   lp->momProjDone = true;
   return MUGIQ_HIP_SUCCESS;
 }
@@ -738,9 +807,14 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
   int st = MUGIQ_HIP_SUCCESS;
   const size_t cb = lp->loopBytes();
   const bool basic = lp->calcType == MUGIQ_HIP_LOOP_CALC_TYPE_BASIC_KERNEL;
+  lp->phases.clear();
+  lp->eventsUsed = 0;
+  const auto tWall0 = std::chrono::steady_clock::now();
   if (lp->coarseMode && lp->fineStore) {
     // prolongateEvec for every eigenvector, once (the reference repeats it per displacement entry, lib/loop_mugiq.cpp:482)
+    const int ph = phase_begin(lp, MUGIQ_HIP_PHASE_PROLONGATION, -1, lp->stream);
     if ((st = mugiq_hip_prolongate_batched(lp->eVecs.data(), lp->coarseVecs.data(), lp->nEv, &lp->transfer, lp->stream))) return st;
+    phase_end(lp, ph, lp->stream);
   }
   // ---- plan (OPT): which entries are reflected from which, and in what order things run.  The slots are independent,
   // so the order of lib/loop_mugiq.cpp:455 is kept for BASIC only; OPT posts the eigenvector halos of all partitioned
@@ -779,6 +853,14 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
         if (lp->derivedFrom[id] < 0 && lp->commDim[dir] && lp->dispStop[id] <= lp->localL[dir])
           if ((st = prepare_halo(lp, id, &budget))) return st;
       }
+      double haloBytes = 0;
+      for (int id = 0; id < lp->nDispEntries; id++)
+        if (lp->halo[id].posted) {
+          // (the transfer cannot start before the last pack kernel: wait here so that the phase brackets the transfer only)
+          MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, lp->halo[id].evPacked, 0));
+          haloBytes += (double)lp->dispStop[id] * 24 * (lp->volumeCB / lp->localL[lp->dispDir[id]]) * lp->cplxBytes() * (double)lp->nEv;
+        }
+      const int phHalo = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_TRANSFER, -1, lp->commStream, haloBytes);
       if (grouped && (st = lp->comm.group_begin(lp->comm.ctx))) return set_error(MUGIQ_HIP_ERROR_HIP, "group_begin callback failed with status %d", st);
       for (int id = 0; id < lp->nDispEntries && !st; id++)
         if (lp->halo[id].posted) st = send_halo(lp, id);
@@ -787,6 +869,7 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
         if (!st && st2) st = set_error(MUGIQ_HIP_ERROR_HIP, "group_end callback failed with status %d", st2);
       }
       if (st) return st;
+      phase_end(lp, phHalo, lp->commStream);
       for (int id = 0; id < lp->nDispEntries; id++)
         if (lp->halo[id].posted) MUGIQ_CHECK_HIP(hipEventRecord(lp->halo[id].evHalo, lp->commStream));
     }
@@ -812,6 +895,13 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
     // displaced contraction write every site of their slots (MUGIQ_HIP_REGION_OVERWRITE).
     const bool stepByStep = id >= 0 && lp->commDim[lp->dispDir[id]] && lp->dispStop[id] > lp->localL[lp->dispDir[id]];
     if (id == -1 || basic || (lp->derivedFrom[id] < 0 && stepByStep)) MUGIQ_CHECK_HIP(hipMemsetAsync(slot0, 0, bufByteSize, lp->stream));
+    const bool reflected = id >= 0 && !basic && lp->derivedFrom[id] >= 0;
+    const bool split = id >= 0 && !basic && !reflected && !stepByStep && lp->commDim[lp->dispDir[id]];  // entry_fused opens its own phases
+    const int ph = split ? -1
+                         : phase_begin(lp, id < 0 ? MUGIQ_HIP_PHASE_ULTRA_LOCAL
+                                                  : reflected ? MUGIQ_HIP_PHASE_ENTRY_REFLECTED
+                                                              : (basic || stepByStep) ? MUGIQ_HIP_PHASE_ENTRY_STEPWISE : MUGIQ_HIP_PHASE_ENTRY_FUSED,
+                                       id, lp->stream);
     if (id == -1 && lp->coarseMode && !lp->fineStore) {
       // MG ultra-local loop without materialising the fine vectors
       st = mugiq_hip_prolongate_contract_batched(slot0, lp->loopPrecision, lp->coarseVecs.data(), lp->sigma.data(), lp->nEv,
@@ -829,11 +919,16 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
       if (basic) st = entry_basic(lp, id, slot0);
       else if (lp->derivedFrom[id] >= 0) st = entry_reflected(lp, id, lp->derivedFrom[id], slot0);
       else st = entry_fused(lp, id, slot0);
-      hipError_t e = hipStreamSynchronize(lp->stream);
+      // No host synchronisation between entries: every user of this entry's scratch is ordered on lp->stream (the halo
+      // stream's part was waited for by the boundary kernels), so the next entry may take the buffers over at once.
       free_scratch(lp);
-      if (!st && e != hipSuccess) st = set_error(MUGIQ_HIP_ERROR_HIP, "computeCoarseLoop: %s", hipGetErrorString(e));
     }
+    phase_end(lp, ph, lp->stream);
     if (st) break;
+  }
+  {
+    hipError_t e = hipStreamSynchronize(lp->stream);
+    if (!st && e != hipSuccess) st = set_error(MUGIQ_HIP_ERROR_HIP, "computeCoarseLoop: %s", hipGetErrorString(e));
   }
   // hand the buffers of the posted halos back (their transfers were waited for by the entries that used them; after an
   // error drain the halo stream first)
@@ -848,8 +943,31 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
   lp->dataPosCopied = false;
   if (lp->doMomProj && (st = momentum_projection(lp))) return st;  // :517-520
   MUGIQ_CHECK_HIP(hipStreamSynchronize(lp->stream));
+  if (lp->profiling) {
+    if (lp->commStream) MUGIQ_CHECK_HIP(hipStreamSynchronize(lp->commStream));
+    phases_resolve(lp);
+    phase_host(lp, MUGIQ_HIP_PHASE_TOTAL_WALL, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tWall0).count());
+  }
   lp->computed = true;
   return MUGIQ_HIP_SUCCESS;
+}
+
+int mugiq_hip_loop_set_profiling(MugiqHipLoop *lp, int on) {
+  MUGIQ_REQUIRE(lp != nullptr, "mugiq_hip_loop_set_profiling: NULL loop handle");
+  lp->profiling = on != 0;
+  return MUGIQ_HIP_SUCCESS;
+}
+
+int mugiq_hip_loop_get_phases(const MugiqHipLoop *lp, MugiqHipLoopPhase *out, int max_phases) {
+  if (!lp) return -MUGIQ_HIP_ERROR_INVALID_ARGUMENT;
+  const int n = (int)lp->phases.size();
+  for (int i = 0; i < n && i < max_phases && out; i++) {
+    out[i].kind = lp->phases[i].kind;
+    out[i].entry = lp->phases[i].entry;
+    out[i].ms = lp->phases[i].ms;
+    out[i].bytes = lp->phases[i].bytes;
+  }
+  return n;
 }
 
 int mugiq_hip_loop_get_info(const MugiqHipLoop *lp, MugiqHipLoopInfo *info) {
@@ -972,6 +1090,7 @@ int mugiq_hip_loop_destroy(MugiqHipLoop *lp) {  // freeDataMemory, lib/loop_mugi
     if (h.evPacked) (void)hipEventDestroy(h.evPacked);
     if (h.evHalo) (void)hipEventDestroy(h.evHalo);
   }
+  for (hipEvent_t e : lp->events) (void)hipEventDestroy(e);
   if (lp->evPacked) (void)hipEventDestroy(lp->evPacked);
   if (lp->evHalo) (void)hipEventDestroy(lp->evHalo);
   if (lp->commStream) (void)hipStreamDestroy(lp->commStream);

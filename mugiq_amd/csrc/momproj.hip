@@ -136,27 +136,6 @@ static int launch_momproj(void *C, const void *A, const void *B, const MomProjGe
   return MUGIQ_HIP_SUCCESS;
 }
 
-static int own_workspace(void **ptr, size_t bytes) {
-  static std::mutex mtx;
-  static void *buf[16] = {nullptr};
-  static size_t cap[16] = {0};
-  std::lock_guard<std::mutex> lock(mtx);
-  int dev = 0;
-  MUGIQ_CHECK_HIP(hipGetDevice(&dev));
-  MUGIQ_REQUIRE(dev >= 0 && dev < 16, "device ordinal %d out of range", dev);
-  if (bytes > cap[dev]) {
-    if (buf[dev]) {
-      MUGIQ_CHECK_HIP(hipDeviceSynchronize());
-      MUGIQ_CHECK_HIP(hipFree(buf[dev]));
-      buf[dev] = nullptr;
-      cap[dev] = 0;
-    }
-    MUGIQ_CHECK_HIP(hipMalloc(&buf[dev], bytes));
-    cap[dev] = bytes;
-  }
-  *ptr = buf[dev];
-  return MUGIQ_HIP_SUCCESS;
-}
 
 
 // ---- separable form of the same projection -------------------------------------------------------------------------
@@ -472,7 +451,7 @@ int mugiq_hip_momentum_projection(void *dataMom_d, const void *dataPosMP_d, cons
   const size_t need = mugiq_hip_momentum_projection_workspace(locT, nData, locV3, Nmom, precision);
   void *ws = workspace_d;
   if (need > 0 && (ws == nullptr || workspace_bytes < need)) {
-    int st = own_workspace(&ws, need);
+    int st = stream_workspace(&ws, need, static_cast<hipStream_t>(stream));
     if (st) return st;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -501,7 +480,7 @@ int mugiq_hip_momentum_projection_separable(void *dataMom_d, const void *dataPos
   const size_t need = mugiq_hip_momentum_projection_separable_workspace(momMatrix_h, Nmom, localL, locT, nData, precision);
   void *ws = workspace_d;
   if (ws == nullptr || workspace_bytes < need) {
-    int st = own_workspace(&ws, need);
+    int st = stream_workspace(&ws, need, static_cast<hipStream_t>(stream));
     if (st) return st;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -528,7 +507,7 @@ int mugiq_hip_convert_and_project(void *dataMom_d, const void *dataPos_d, int nD
   const size_t need = mugiq_hip_momentum_projection_separable_workspace(momMatrix_h, Nmom, localL, locT, nData, precision);
   void *ws = workspace_d;
   if (ws == nullptr || workspace_bytes < need) {
-    int st = own_workspace(&ws, need);
+    int st = stream_workspace(&ws, need, static_cast<hipStream_t>(stream));
     if (st) return st;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);

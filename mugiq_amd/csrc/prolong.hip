@@ -502,9 +502,9 @@ static int coarse_plan(const MugiqHipTransfer *T, const MugiqHipCoarseField *coa
   const size_t tabBytes = (pb + sizeof(A) * (size_t)nVec + 255) / 256 * 256;
   const size_t cBytes = sizeof(Cplx<A>) * (size_t)volc * NC * NC;
   // one scratch region holds [pointer table | 1/sigma | C]: reserve it in full first, so that the table upload below
-  // (which draws on the same per-device scratch) cannot move it
+  // (which draws on the same per-stream scratch) cannot move it
   void *base = nullptr;
-  int st = device_scratch(&base, tabBytes + cBytes);
+  int st = stream_scratch(&base, tabBytes + cBytes, stream);
   if (st) return st;
   std::vector<unsigned char> host(tabBytes, 0);
   const void **hc = reinterpret_cast<const void **>(host.data());

@@ -182,10 +182,10 @@ int mugiq_hip_create_phase_matrix(void *phaseMatrix_d, const int *momMatrix_h, l
 int mugiq_hip_probe_read_bandwidth(const void *buf_d, size_t bytes, int nonTemporal, void *stream) {
   MUGIQ_REQUIRE(buf_d != nullptr && bytes >= 16 && (reinterpret_cast<uintptr_t>(buf_d) & 15) == 0,
                 "mugiq_hip_probe_read_bandwidth: need a 16-byte aligned buffer of >= 16 bytes");
-  void *sink = nullptr;
-  int st = device_scratch(&sink, 64);
-  if (st) return st;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  void *sink = nullptr;
+  int st = stream_scratch(&sink, 64, s);
+  if (st) return st;
   const size_t n16 = bytes / 16;
   const unsigned grid = 256 * 16;  // 16 workgroups of 256 lanes per CU
   if (nonTemporal)

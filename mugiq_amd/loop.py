@@ -34,6 +34,15 @@ class _CLoopInfo(ctypes.Structure):
                 ("nElemMomLoc", ctypes.c_longlong), ("nElemMomTot", ctypes.c_longlong), ("nElemPhMat", ctypes.c_longlong)]
 
 
+class _CLoopPhase(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("entry", ctypes.c_int), ("ms", ctypes.c_double), ("bytes", ctypes.c_double)]
+
+
+PHASE_NAMES = ["ultra_local", "entry_fused", "entry_reflected", "entry_stepwise", "momentum_projection", "halo_transfer",
+               "entry_interior", "entry_boundary", "prolongation", "halo_prepare", "halo_wait", "momentum_copy",
+               "momentum_reduce", "total_wall"]                           # MUGIQ_HIP_PHASE_* (include/mugiq_hip.h)
+
+
 @dataclass
 class MugiqLoopParam:
     """include/mugiq.h:28-47.  `gauge` is the border-extended device GaugeField (the reference passes host QDP
@@ -215,6 +224,21 @@ class Loop_Mugiq:
         """After computeCoarseLoop: the entry that entry `idx` was reflected from (opposite sign, same direction and
         lengths), or -1 if it was computed from the eigenvectors."""
         return int(_lib.load().mugiq_hip_loop_entry_derived_from(self._handle, int(idx)))
+
+    def setProfiling(self, on=True):
+        """Bracket every phase of the next computeCoarseLoop with HIP events (mugiq_hip_loop_set_profiling)."""
+        _lib.check(_lib.load().mugiq_hip_loop_set_profiling(self._handle, int(bool(on))))
+        return self
+
+    def phases(self):
+        """[{kind, entry, ms, bytes}] of the last computeCoarseLoop, in issue order (empty unless setProfiling was on)."""
+        lib = _lib.load()
+        n = lib.mugiq_hip_loop_get_phases(self._handle, None, 0)
+        if n <= 0:
+            return []
+        buf = (_CLoopPhase * n)()
+        lib.mugiq_hip_loop_get_phases(self._handle, ctypes.cast(buf, ctypes.c_void_p), n)
+        return [{"kind": PHASE_NAMES[b.kind], "entry": b.entry, "ms": b.ms, "bytes": b.bytes} for b in buf]
 
     def computeCoarseLoop(self):
         """lib/loop_mugiq.cpp:439-525"""

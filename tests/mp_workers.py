@@ -54,13 +54,12 @@ def _check_pos(orc, rank_coord, grid, G, l, cprm, pos_local, pos_global, tol):
         assert e < tol, ("dataPos", idata, e)
 
 
-def cpu_worker(rank, world, port, grid):
+def cpu_worker(rank, world, port, grid, G=(4, 4, 4, 8)):
     """N>1 path on CPU: GridComm over gloo + oracle arithmetic == single-domain oracle."""
     import torch
     from util import orc, momenta_p2_le, rel_err
     dist = _init(rank, world, port)
     from mugiq_amd.comm import GridComm
-    G = (4, 4, 4, 8)
     disp = (["+t", "-t", "+z", "-x"], [1, 1, 2, 1], [2, 1, 2, 1])
     moms = momenta_p2_le(2)
     FTSign = -1
@@ -160,6 +159,78 @@ def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8), 
     _check_pos(orc, comm.coord, grid, G, l, cprm, loop.dataPos_d.cpu().numpy().astype(np.complex128), pos_g, tol)
     e = rel_err(loop.dataMom_global(), mom_g)
     assert e < tol, ("dataMom", e)
+    loop.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def nccl_world1_worker(rank, world, port, loopback):
+    """ONE rank on the nccl (= RCCL) backend: every GridComm operation with the buffers and on the streams the driver
+    uses them with -- host payloads of the FT reduction through _wire (device round trip + RCCL reduce / all_gather /
+    broadcast), device halos through the C callbacks on a side stream (the ExternalStream branch), a transfer group, and
+    a whole driver run with a comm handed in.  loopback: also send the halo to self through RCCL's isend / irecv."""
+    import ctypes
+    import torch
+    from util import orc, momenta_p2_le, rel_err
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import mugiq_amd as hip
+    comm = hip.GridComm((1, 1, 1, 1), device=dev)
+    assert comm.backend == "nccl" and comm.is_time_process and comm.space_root == 0
+    for dt in (torch.float64, torch.float32):                       # reduce_space / gather_time / bcast: lib/loop_mugiq.cpp:406-424
+        send = torch.arange(1, 4097, dtype=dt) / 7
+        red = torch.zeros_like(send)
+        comm.reduce_space(send, red)
+        assert torch.equal(red, send)
+        full = torch.zeros_like(send)
+        comm.gather_time(red, full)
+        assert torch.equal(full, send)
+        b = full.clone()
+        comm.bcast(b)
+        assert torch.equal(b, send)
+    # device halos through the C callbacks, on a stream that is NOT torch's current one
+    c = comm.c_struct()
+    side = torch.cuda.Stream()
+    n = 1 << 20
+    a = torch.randn(n, dtype=torch.float64, device=dev)
+    r = torch.zeros_like(a)
+    torch.cuda.synchronize()
+    comm.loopback_through_transport = bool(loopback)
+    with torch.cuda.stream(side):
+        a2 = a * 2                                                   # producer on the side stream; the exchange must order after it
+    assert c.sendrecv(None, a2.data_ptr(), r.data_ptr(), n * 8, 3, +1, side.cuda_stream) == 0
+    side.synchronize()
+    assert torch.equal(r, a * 2)
+    r.zero_()
+    r2 = torch.zeros_like(a)
+    assert c.group_begin(None) == 0                                  # two halos of different axes in one transfer group
+    assert c.sendrecv(None, a.data_ptr(), r.data_ptr(), n * 8, 3, -1, side.cuda_stream) == 0
+    assert c.sendrecv(None, a2.data_ptr(), r2.data_ptr(), n * 8, 2, +1, side.cuda_stream) == 0
+    assert c.group_end(None, side.cuda_stream) == 0
+    side.synchronize()
+    assert torch.equal(r, a) and torch.equal(r2, a * 2)
+    comm.loopback_through_transport = False
+    # the driver with a communicator on a 1x1x1x1 grid == the driver without one == the oracle
+    X = (4, 4, 4, 8)
+    ev_lex, U_lex, sg = _global_problem(X, 3, 5)
+    moms = momenta_p2_le(2)
+    disp = (["+t", "-t", "+z"], [1, 1, 2], [2, 2, 2])
+    cprm, pos_g, mom_g = _single_domain_reference(orc, X, ev_lex, U_lex, sg, disp, moms, -1)
+    U_loc = np.stack([orc.lex_to_eo(U_lex[mu], X) for mu in range(4)])
+    gauge = hip.GaugeField(X, (0, 0, 0, 0), 8).set_from_qdp_host(orc.gauge_to_qdp_host(U_loc), comm)
+    f = [hip.SpinorField(X, 8, 2).set_logical(orc.lex_to_eo(v, X)) for v in ev_lex]
+    prm = hip.MugiqLoopParam(Nmom=len(moms), momMatrix=[list(m) for m in moms], FTSign=-1, doMomProj=True, doNonLocal=True,
+                             disp_str=disp[0], disp_start=disp[1], disp_stop=disp[2], gauge=gauge)
+    loop = hip.Loop_Mugiq(prm, f, sg, comm).setProfiling()
+    loop.computeCoarseLoop()
+    assert rel_err(loop.dataPos_d.cpu().numpy(), pos_g) < 1e-12
+    assert rel_err(loop.dataMom_global(), mom_g) < 1e-12
+    kinds = [p["kind"] for p in loop.phases()]
+    assert kinds[0] == "ultra_local" and "momentum_projection" in kinds and kinds[-1] == "total_wall", kinds
     loop.close()
     dist.barrier()
     dist.destroy_process_group()

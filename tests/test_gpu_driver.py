@@ -171,6 +171,19 @@ def test_four_rank_driver_z_and_t_partitioned_on_one_gpu():
     mp.spawn(mp_workers.gpu_worker, args=(4, free_port(), (1, 1, 2, 2), 8, 2, 1), nprocs=4, join=True)
 
 
+@pytest.mark.parametrize("grid,G,prec,order,calc,ahead", [((1, 1, 1, 4), (4, 4, 4, 16), 8, 2, 1, "1"), ((1, 1, 1, 4), (4, 4, 4, 16), 8, 2, 1, "0"),
+                                                          ((1, 1, 1, 4), (4, 4, 4, 16), 4, 4, 2, "1"), ((1, 1, 4, 1), (4, 4, 16, 4), 8, 4, 1, "1"),
+                                                          ((4, 1, 1, 1), (16, 4, 4, 4), 4, 2, 1, "0")])
+def test_four_rank_driver_extent_four_grid_on_one_gpu(grid, G, prec, order, calc, ahead, monkeypatch):
+    """A process grid with extent 4 along one axis (configs[2] is 1x1x2x4): the forward and the backward neighbour are
+    DIFFERENT ranks, so a swapped send direction in exchange_face / send_halo / entry_reflected / the extended-gauge
+    setup would fail here (with extent 2 both neighbours are the same rank).  Local extent 4: lengths 1..3 go through the
+    multi-layer halo (OPT; posted ahead or not), '-' entries are reflected from '+' ones, length 5 takes the step-by-step
+    sequence; calc 2 = BASIC (the reference's sequence: one face per step)."""
+    monkeypatch.setenv("MUGIQ_HIP_HALO_AHEAD", ahead)
+    mp.spawn(mp_workers.gpu_worker, args=(4, free_port(), grid, prec, order, calc, G), nprocs=4, join=True)
+
+
 def test_driver_writes_reference_hdf5_tree(hip, tmp_path):
     """computeLoop -> writeLoopsHDF5 (lib/interface_mugiq.cpp:158-172): file contents == dataMom_bcast."""
     import h5read

@@ -24,3 +24,15 @@ def test_two_rank_gloo_loop_equals_single_domain(grid):
 
 def test_four_rank_gloo_z_and_t_partitioned():
     mp.spawn(mp_workers.cpu_worker, args=(4, free_port(), (1, 1, 2, 2)), nprocs=4, join=True)
+
+
+@pytest.mark.parametrize("grid,G", [((1, 1, 1, 4), (4, 4, 4, 8)), ((1, 1, 4, 1), (4, 4, 8, 4))])
+def test_four_rank_gloo_extent_four(grid, G):
+    """Extent 4 along one axis: the +1 and -1 neighbours are different ranks (with extent 2 they coincide, and a swapped
+    send direction could not fail)."""
+    mp.spawn(mp_workers.cpu_worker, args=(4, free_port(), grid, G), nprocs=4, join=True)
+
+
+def test_eight_rank_gloo_baseline_grid():
+    """BASELINE.json configs[2]'s process grid, 1 x 1 x 2 x 4 (z and t partitioned, t extent 4), on 8 gloo ranks."""
+    mp.spawn(mp_workers.cpu_worker, args=(8, free_port(), (1, 1, 2, 4)), nprocs=8, join=True)

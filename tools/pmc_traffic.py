@@ -7,8 +7,19 @@ coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-B-per-lane strea
 usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel-substring> <workload> <out.json>
 """
 import csv
+import hashlib
 import json
+import os
 import sys
+
+
+def source_fingerprint():
+    """the same fingerprint bench.py computes: sha1 over the sources of the headline kernel"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha1()
+    for f in ("contract.hip", "internal.h"):
+        h.update(open(os.path.join(root, "mugiq_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
 
 
 def mean_counter(path, kernel, name):
@@ -21,7 +32,7 @@ fetch_csv, write_csv, kernel, workload, out = sys.argv[1:6]
 f, nf = mean_counter(fetch_csv, kernel, "FETCH_SIZE")
 w, nw = mean_counter(write_csv, kernel, "WRITE_SIZE")
 res = {
-    "workload": workload, "kernel": kernel, "launches_averaged": [nf, nw],
+    "workload": workload, "kernel": kernel, "launches_averaged": [nf, nw], "source_fingerprint": source_fingerprint(),
     "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB_raw": w,
     "fetch_bytes_corrected_x2": 2.0 * f * 1024.0, "write_bytes": w * 1024.0,
     "hbm_bytes_per_launch": 2.0 * f * 1024.0 + w * 1024.0,
