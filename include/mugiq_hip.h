@@ -294,17 +294,18 @@ typedef struct MugiqHipCoarseField_s {
   int64_t parity_offset;
 } MugiqHipCoarseField;
 
-/* One level of QUDA's Transfer: the block-orthonormal null vectors V as a fine field with a packed vector index,
- * FieldOrderCB<Float,4,3,n_vec,FLOAT2>: complex index of V(parity, x_cb; s, c, j) =
- * parity*parity_offset + ((3*s + c)*nVec + j)*stride + x_cb.  (Producing V is QUDA's MG setup: out of scope.) */
+/* One level of QUDA's Transfer: the block-orthonormal null vectors V as a field of the FINER side with a packed vector
+ * index.  Finest level: FieldOrderCB<Float,4,3,n_vec,FLOAT2>, complex index of V(parity, x_cb; s, c, j) =
+ * parity*parity_offset + ((3*s + c)*nVec + j)*stride + x_cb, spinBlockSize 2.  Coarse -> coarse levels: see
+ * mugiq_hip_prolongate_coarse_batched.  (Producing V is QUDA's MG setup: out of scope.) */
 typedef struct MugiqHipTransfer_s {
   const void *V;
   int precision;       /* 4 | 8 */
   int nVec;            /* mg_param.n_vec[0], default 24 (tests/loop.cpp:492) */
   int geoBlockSize[4]; /* mg_param.geo_block_size[0], default 4^4 (tests/loop.cpp:471) */
   int spinBlockSize;   /* 2 (tests/loop.cpp:569) */
-  int X[4];            /* fine local dims */
-  int stride;          /* fine volumeCB + pad */
+  int X[4];            /* local dims of the finer side of this level */
+  int stride;          /* volumeCB of the finer side + pad */
   int64_t parity_offset;
 } MugiqHipTransfer;
 
@@ -312,6 +313,14 @@ typedef struct MugiqHipTransfer_s {
  * (the reference prolongs one eigenvector per call, and again for every displacement entry: lib/loop_mugiq.cpp:482). */
 int mugiq_hip_prolongate_batched(const MugiqHipSpinorField *fine_h, const MugiqHipCoarseField *coarse_h, int nVec,
                                  const MugiqHipTransfer *transfer, void *stream);
+/* One COARSE -> COARSE level of the hierarchy (mg_env.transfer[lev], lev >= 1; Loop_Mugiq::prolongateEvec walks them from
+ * the coarsest level up before the finest transfer, lib/loop_mugiq.cpp:306-311).  Both sides are coarse fields with
+ * nSpin = 2: out_h[n](x; s, c) = sum_j V(x; s, c, j) * in_h[n](X(x); s, j), with `transfer` describing this level:
+ * X = dims of the FINER of the two lattices (= out_h[n].X), geoBlockSize, nVec = in_h[n].nColor, spinBlockSize = 1, and
+ * V = FieldOrderCB<Float, 2, out_h[n].nColor, nVec, FLOAT2>: complex index parity*parity_offset +
+ * ((out.nColor*s + c)*nVec + j)*stride + x_cb.  All nVec eigenvectors in one launch. */
+int mugiq_hip_prolongate_coarse_batched(const MugiqHipCoarseField *out_h, const MugiqHipCoarseField *in_h, int nVec,
+                                        const MugiqHipTransfer *transfer, void *stream);
 /* Ultra-local loop of the MG path without materialising the fine vectors:
  * loopData += sum_n (1/sigma_n) (P c_n)^dag G (P c_n).  loopPrecision as in the *_mixed entry points. */
 int mugiq_hip_prolongate_contract_batched(void *loopData_d, int loopPrecision, const MugiqHipCoarseField *coarse_h,
@@ -411,6 +420,14 @@ int mugiq_hip_loop_create_coarse(MugiqHipLoop **loop, const MugiqHipLoopParam *p
                                  const MugiqHipCoarseField *coarseEvecs_h, const double *eVals_sigma_h, int nEv,
                                  const MugiqHipTransfer *transfer, int fineFieldOrder, const MugiqHipComm *comm,
                                  void *stream);
+/* The same for an MG hierarchy with nCoarseLevels = mg_param.n_level - 1 >= 1 coarse levels (include/mg_mugiq.h:20,30): the
+ * eigenvectors live on the COARSEST level; transfers_h[0] is the finest transfer (fine lattice <-> level 1, spinBlockSize 2),
+ * transfers_h[l], l >= 1, the one between level l and level l+1 (see mugiq_hip_prolongate_coarse_batched).  Every compute
+ * prolongs all eigenvectors level by level (lib/loop_mugiq.cpp:306-314) into temporaries the loop object owns. */
+int mugiq_hip_loop_create_coarse_levels(MugiqHipLoop **loop, const MugiqHipLoopParam *param,
+                                        const MugiqHipCoarseField *coarsestEvecs_h, const double *eVals_sigma_h, int nEv,
+                                        const MugiqHipTransfer *transfers_h, int nCoarseLevels, int fineFieldOrder,
+                                        const MugiqHipComm *comm, void *stream);
 /* Loop_Mugiq::computeCoarseLoop()  lib/loop_mugiq.cpp:439-525 (position-space loops for the ultra-local case and
  * every displacement entry, then performMomentumProjection :322-434 if doMomProj).  Synchronises `stream`. */
 int mugiq_hip_loop_compute(MugiqHipLoop *loop);
@@ -469,6 +486,11 @@ int mugiq_hip_loop_destroy(MugiqHipLoop *loop);
 /* ---- a6 (setup): Displace::createExtendedCudaGaugeField  lib/displace.cpp:70-134 ------------------------------------ */
 /* bytes of a pad-0 extended field: volExCB * 36 * 2 parities * sizeof(complex) */
 size_t mugiq_hip_extended_gauge_bytes(const int X[4], const int R[4], int precision);
+/* Allocate (zeroed, pad 0) and describe the extended field for local dims X and border R -- gParamEx of
+ * lib/displace.cpp:104-124 -- for hosts that do not manage device memory themselves; release with
+ * mugiq_hip_free_extended_gauge. */
+int mugiq_hip_alloc_extended_gauge(MugiqHipGaugeField *gauge, const int X[4], const int R[4], int precision);
+int mugiq_hip_free_extended_gauge(MugiqHipGaugeField *gauge);
 /* Fill gauge->data (device, caller-allocated, descriptor complete) from the host links of the LOCAL lattice in
  * QDP order, qdpLinks_h[dir][(parity*V/2 + x_cb)*18 + (row*3+col)*2 + re/im] of cpuPrecision (4|8)
  * (loopParams.gauge[4], tests/loop.cpp:88,106,902-918), then fill the R-deep borders: neighbour slabs through

@@ -7,13 +7,14 @@
 // Loop_Mugiq<Float,order> (include/loop_mugiq.h:123-134).  Where the reference aborts through errorQuda, these
 // throw mugiq_hip::Error carrying the same message.  Header-only; link with -lmugiq_hip.
 //
-// Inside a MuGiq/QUDA build define MUGIQ_HIP_NO_REFERENCE_ENUMS (MuGiq's own enum_mugiq.h provides the enums)
-// and use the adapter of INTEGRATION.md to produce the descriptors from QUDA fields.
+// Inside a MuGiq/QUDA build include mugiq_hip_quda_adapter.hpp instead: it defines MUGIQ_HIP_NO_REFERENCE_ENUMS (MuGiq's own
+// enum_mugiq.h provides the enums) and MUGIQ_HIP_WITH_QUDA, and produces the descriptors from QUDA fields.
 #ifndef MUGIQ_HIP_OPERATORS_HPP
 #define MUGIQ_HIP_OPERATORS_HPP
 
 #include <climits>
 #include <complex>
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -135,7 +136,22 @@ inline std::string GammaName(int m) {
   return s;
 }
 
-// include/mugiq.h:28-47 (the reference passes host QDP links + QudaGaugeParam; here the extended device field)
+// The members of QudaGaugeParam this path reads (lib/displace.cpp:70-99: local lattice, host and device precision).
+// Inside a QUDA build (MUGIQ_HIP_WITH_QUDA, see mugiq_hip_quda_adapter.hpp) it IS QudaGaugeParam: same member names.
+#ifdef MUGIQ_HIP_WITH_QUDA
+using GaugeParam = QudaGaugeParam;
+#else
+struct GaugeParam {
+  int X[4];       // local lattice dimensions
+  int cpu_prec;   // precision of the host links: 4 | 8 (QUDA_SINGLE/DOUBLE_PRECISION have these values)
+  int cuda_prec;  // precision of the device field: must equal sizeof(Float) of the loop (lib/displace.cpp:84-87)
+};
+#endif
+
+// include/mugiq.h:28-47, member for member: `gauge` are the four host arrays of the LOCAL lattice in QDP order
+// (gauge[dir][(parity*V/2 + x_cb)*18 + (row*3+col)*2 + re/im], tests/loop.cpp:88,106,902-918) and `gauge_param` their
+// description; Loop_Mugiq builds the border-extended device field from them as Displace does (lib/displace.cpp:70-134).
+// gauge_ext (not in the reference) hands over an extended device field that already exists instead.
 struct MugiqLoopParam {
   int Nmom = 0;
   std::vector<std::vector<int>> momMatrix;  // [Nmom][3]
@@ -151,7 +167,10 @@ struct MugiqLoopParam {
   std::string fname_pos_h5;
   std::vector<int> disp_start;
   std::vector<int> disp_stop;
-  const GaugeField *gauge = nullptr;
+  void *gauge[4] = {nullptr, nullptr, nullptr, nullptr};
+  GaugeParam *gauge_param = nullptr;
+  const GaugeField *gauge_ext = nullptr;
+  int loopPrecision = 0;  // not in the reference: 8 over fp32 eigenvectors = mixed precision
 };
 
 // tests/loop.cpp:656-705
@@ -179,45 +198,98 @@ inline void setDisplaceEntryString(MugiqLoopParam &p, const std::string &entries
 // `eVecs` / `eVals_sigma` are what the reference reads from Eigsolve_Mugiq as a friend (lib/loop_mugiq.cpp:442,479).
 template <typename Float, int fieldOrder> class Loop_Mugiq {
   MugiqHipLoop *h_ = nullptr;
+  GaugeField ownGauge_{};  // Displace::gaugeField when built here from loopParams.gauge[4]
 
-public:
-  Loop_Mugiq(MugiqLoopParam *lp, const std::vector<ColorSpinorField> &eVecs, const std::vector<double> &eVals_sigma,
-             const MugiqHipComm *comm = nullptr, void *stream = nullptr) {
-    if (eVecs.empty() || eVecs.size() != eVals_sigma.size()) throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "Loop_Mugiq: eVecs / eVals_sigma size mismatch");
-    checkField<Float, fieldOrder>(&eVecs[0], "Loop_Mugiq");
+  // everything the C parameter block points into, alive for the duration of the create call
+  struct CParam {
     std::vector<int> mom;
+    std::vector<const char *> ent, str;
+    MugiqHipLoopParam p{};
+  };
+  void fill(CParam &c, MugiqLoopParam *lp, const MugiqHipComm *comm, void *stream) {
     for (auto &m : lp->momMatrix) {
       if (m.size() != 3) throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "Loop_Mugiq: momMatrix rows must have 3 entries");
-      mom.insert(mom.end(), m.begin(), m.end());
+      c.mom.insert(c.mom.end(), m.begin(), m.end());
     }
-    std::vector<const char *> ent, str;
-    for (auto &s : lp->disp_entry) ent.push_back(s.c_str());
-    for (auto &s : lp->disp_str) str.push_back(s.c_str());
-    ent.resize(str.size(), "");
+    for (auto &s : lp->disp_entry) c.ent.push_back(s.c_str());
+    for (auto &s : lp->disp_str) c.str.push_back(s.c_str());
+    c.ent.resize(c.str.size(), "");
     if (lp->disp_str.size() != lp->disp_start.size() || lp->disp_str.size() != lp->disp_stop.size())
       throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "Displacement string length not compatible with displacement limits length");
-    MugiqHipLoopParam p{};
+    MugiqHipLoopParam &p = c.p;
     p.Nmom = lp->Nmom ? lp->Nmom : (int)lp->momMatrix.size();
-    p.momMatrix = mom.empty() ? nullptr : mom.data();
+    p.momMatrix = c.mom.empty() ? nullptr : c.mom.data();
     p.FTSign = (int)lp->FTSign;
     p.calcType = (int)lp->calcType;
     p.writeMomSpaceHDF5 = lp->writeMomSpaceHDF5 == MUGIQ_BOOL_TRUE;
     p.writePosSpaceHDF5 = lp->writePosSpaceHDF5 == MUGIQ_BOOL_TRUE;
     p.doMomProj = lp->doMomProj == MUGIQ_BOOL_TRUE;
     p.doNonLocal = lp->doNonLocal == MUGIQ_BOOL_TRUE;
-    p.nDispEntries = (int)str.size();
-    p.disp_entry = ent.data();
-    p.disp_str = str.data();
+    p.nDispEntries = (int)c.str.size();
+    p.disp_entry = c.ent.data();
+    p.disp_str = c.str.data();
     p.disp_start = lp->disp_start.data();
     p.disp_stop = lp->disp_stop.data();
     p.fname_mom_h5 = lp->fname_mom_h5.c_str();
     p.fname_pos_h5 = lp->fname_pos_h5.c_str();
-    p.gauge = lp->gauge;
-    check(mugiq_hip_loop_create(&h_, &p, eVecs.data(), eVals_sigma.data(), (int)eVecs.size(), comm, stream));
+    p.loopPrecision = lp->loopPrecision;
+    p.gauge = lp->gauge_ext;
+    if (p.doNonLocal && p.nDispEntries > 0 && !p.gauge && lp->gauge[0] && lp->gauge_param) {
+      // Displace::Displace + createExtendedCudaGaugeField (lib/displace.cpp:6-37,70-134)
+      const GaugeParam &gp = *lp->gauge_param;
+      if ((int)gp.cuda_prec != precisionOf<Float>())
+        throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "createCudaGaugeField: Incompatible precision settings between Displace template and gauge field parameters");
+      int X[4], R[4];
+      for (int d = 0; d < 4; d++) {
+        X[d] = gp.X[d];
+        R[d] = 2 * ((comm && comm->grid[d] > 1) ? 1 : 0);  // exRng[i] = 2 * redundantComms-or-commDimPartitioned, lib/displace.cpp:16
+      }
+      check(mugiq_hip_alloc_extended_gauge(&ownGauge_, X, R, precisionOf<Float>()));
+      const void *links[4] = {lp->gauge[0], lp->gauge[1], lp->gauge[2], lp->gauge[3]};
+      const int st = mugiq_hip_create_extended_gauge(&ownGauge_, links, (int)gp.cpu_prec, comm, stream);
+      if (st) {
+        mugiq_hip_free_extended_gauge(&ownGauge_);
+        check(st);
+      }
+      p.gauge = &ownGauge_;
+    }
+  }
+
+public:
+  Loop_Mugiq(MugiqLoopParam *lp, const std::vector<ColorSpinorField> &eVecs, const std::vector<double> &eVals_sigma,
+             const MugiqHipComm *comm = nullptr, void *stream = nullptr) {
+    if (eVecs.empty() || eVecs.size() != eVals_sigma.size()) throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "Loop_Mugiq: eVecs / eVals_sigma size mismatch");
+    checkField<Float, fieldOrder>(&eVecs[0], "Loop_Mugiq");
+    CParam c;
+    fill(c, lp, comm, stream);
+    const int st = mugiq_hip_loop_create(&h_, &c.p, eVecs.data(), eVals_sigma.data(), (int)eVecs.size(), comm, stream);
+    if (st) {
+      mugiq_hip_free_extended_gauge(&ownGauge_);
+      check(st);
+    }
+  }
+  // eigsolve->useMGenv && eigsolve->computeCoarse (lib/loop_mugiq.cpp:42,277-319,482): coarse eigenvectors on the coarsest
+  // level of the hierarchy + mg_env->transfer[0 .. nCoarseLevels)
+  Loop_Mugiq(MugiqLoopParam *lp, const std::vector<MugiqHipCoarseField> &coarseEvecs, const std::vector<double> &eVals_sigma,
+             const std::vector<MugiqHipTransfer> &transfers, const MugiqHipComm *comm = nullptr, void *stream = nullptr) {
+    if (coarseEvecs.empty() || coarseEvecs.size() != eVals_sigma.size() || transfers.empty())
+      throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "Loop_Mugiq: coarse eVecs / eVals_sigma / transfer size mismatch");
+    if (fieldOrder != FLOAT2_FIELD_ORDER) throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "prolongateEvec: Vector prolongation requires fieldOrder = FLOAT2");
+    CParam c;
+    fill(c, lp, comm, stream);
+    const int st = mugiq_hip_loop_create_coarse_levels(&h_, &c.p, coarseEvecs.data(), eVals_sigma.data(), (int)coarseEvecs.size(),
+                                                       transfers.data(), (int)transfers.size(), fieldOrder, comm, stream);
+    if (st) {
+      mugiq_hip_free_extended_gauge(&ownGauge_);
+      check(st);
+    }
   }
   Loop_Mugiq(const Loop_Mugiq &) = delete;
   Loop_Mugiq &operator=(const Loop_Mugiq &) = delete;
-  ~Loop_Mugiq() { mugiq_hip_loop_destroy(h_); }
+  ~Loop_Mugiq() {
+    mugiq_hip_loop_destroy(h_);
+    mugiq_hip_free_extended_gauge(&ownGauge_);
+  }
 
   void computeCoarseLoop() { check(mugiq_hip_loop_compute(h_)); }  // lib/loop_mugiq.cpp:439-525
   void writeLoopsHDF5() { check(mugiq_hip_loop_write_hdf5(h_)); }  // lib/loop_mugiq.cpp:668-693
@@ -227,6 +299,7 @@ public:
     check(mugiq_hip_loop_get_info(h_, &i));
     return i;
   }
+  MugiqHipLoop *handle() { return h_; }
   const std::complex<Float> *dataPos_d() const { return static_cast<const std::complex<Float> *>(mugiq_hip_loop_data_pos_d(h_)); }
   const std::complex<Float> *dataPos() { return static_cast<const std::complex<Float> *>(mugiq_hip_loop_data_pos_h(h_)); }
   const std::complex<Float> *dataMom_bcast() const { return static_cast<const std::complex<Float> *>(mugiq_hip_loop_data_mom_bcast_h(h_)); }
@@ -239,6 +312,7 @@ inline void computeLoop(MugiqLoopParam loopParams, const std::vector<ColorSpinor
   Loop_Mugiq<Float, fieldOrder> loop(&loopParams, eVecs, eVals_sigma, comm, stream);
   loop.computeCoarseLoop();
   if (loopParams.writeMomSpaceHDF5 != MUGIQ_BOOL_FALSE || loopParams.writePosSpaceHDF5 != MUGIQ_BOOL_FALSE) loop.writeLoopsHDF5();
+  else fprintf(stderr, "computeLoop: Will NOT write output data!\n");  // warningQuda, lib/interface_mugiq.cpp:167
 }
 
 }  // namespace mugiq_hip

@@ -11,7 +11,7 @@ from .fields import SpinorField, GaugeField, CoarseField, Transfer, FLOAT2, FLOA
 from .operators import (  # noqa: E402
     copyGammaCoeffStructToSymbol, copyGammaMapStructToSymbol, gammaTables, GammaName,
     performLoopContraction, performLoopContractionBatched, performCovariantDisplacementVector, packFace,
-    createPhaseMatrixGPU, convertIdxOrder_mapGamma, momentumProjection, momentumProjectionSeparable, convertAndProject, packFaceLayers, displacedLoopContractionFused, reflectDisplacedLoop, packLoopLayers, probeReadBandwidth, prolongateEvecs, prolongateContractBatched,
+    createPhaseMatrixGPU, convertIdxOrder_mapGamma, momentumProjection, momentumProjectionSeparable, convertAndProject, packFaceLayers, displacedLoopContractionFused, reflectDisplacedLoop, packLoopLayers, probeReadBandwidth, prolongateEvecs, prolongateCoarseEvecs, prolongateContractBatched,
     DispDir, DispSignMinus, DispSignPlus, LOOP_FT_SIGN_MINUS, LOOP_FT_SIGN_PLUS, DisplaceFlagArray,
 )
 from ._lib import MugiqHipError, LIB_PATH  # noqa: E402

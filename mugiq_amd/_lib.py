@@ -107,6 +107,11 @@ SIGNATURES = {
     # driver (struct pointers are passed with ctypes.byref; see mugiq_amd/loop.py for the struct definitions)
     "mugiq_hip_loop_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _VP, _SP, ctypes.POINTER(ctypes.c_double),
                                              ctypes.c_int, _VP, _VP]),
+    "mugiq_hip_loop_create_coarse_levels": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _VP, ctypes.POINTER(CoarseDesc),
+                                                           ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.POINTER(TransferDesc),
+                                                           ctypes.c_int, ctypes.c_int, _VP, _VP]),
+    "mugiq_hip_prolongate_coarse_batched": (ctypes.c_int, [ctypes.POINTER(CoarseDesc), ctypes.POINTER(CoarseDesc), ctypes.c_int,
+                                                           ctypes.POINTER(TransferDesc), _VP]),
     "mugiq_hip_loop_create_coarse": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _VP, ctypes.POINTER(CoarseDesc),
                                                     ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.POINTER(TransferDesc),
                                                     ctypes.c_int, _VP, _VP]),
@@ -124,6 +129,8 @@ SIGNATURES = {
                                                       ctypes.POINTER(ctypes.c_char_p), _I4, _I4, ctypes.c_int, ctypes.c_int]),
     "mugiq_hip_loop_destroy": (ctypes.c_int, [_VP]),
     "mugiq_hip_extended_gauge_bytes": (ctypes.c_size_t, [_I4, _I4, ctypes.c_int]),
+    "mugiq_hip_alloc_extended_gauge": (ctypes.c_int, [_GP, _I4, _I4, ctypes.c_int]),
+    "mugiq_hip_free_extended_gauge": (ctypes.c_int, [_GP]),
     "mugiq_hip_create_extended_gauge": (ctypes.c_int, [_GP, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _VP, _VP]),
     "mugiq_hip_parse_displace_entry_string": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, _I4, _I4]),
     "mugiq_hip_parse_displacement": (ctypes.c_int, [ctypes.c_char_p, _I4, _I4]),

@@ -154,6 +154,38 @@ size_t mugiq_hip_extended_gauge_bytes(const int X[4], const int R[4], int precis
   return vol / 2 * 36 * 2 * 2 * (size_t)precision;  // volExCB * 36 planes * 2 parities * complex
 }
 
+// the allocation half of Displace::createExtendedCudaGaugeField (lib/displace.cpp:104-124: gParamEx from X + 2 r, pad 0,
+// QUDA_ZERO_FIELD_CREATE), for hosts that do not manage device memory themselves
+int mugiq_hip_alloc_extended_gauge(MugiqHipGaugeField *gauge, const int X[4], const int R[4], int precision) {
+  const char *who = "createExtendedCudaGaugeField";
+  MUGIQ_REQUIRE(gauge && X && R, "%s: NULL argument", who);
+  MUGIQ_REQUIRE(precision == 4 || precision == 8, "%s: precision %d", who, precision);
+  long long volEx = 1;
+  for (int d = 0; d < 4; d++) {
+    MUGIQ_REQUIRE(X[d] > 0 && (X[d] & 1) == 0 && R[d] >= 0, "%s: X[%d] = %d must be positive and even, R[%d] = %d non-negative", who, d, X[d], d, R[d]);
+    gauge->X[d] = X[d];
+    gauge->R[d] = R[d];
+    volEx *= X[d] + 2 * R[d];
+  }
+  MUGIQ_REQUIRE(volEx / 2 < (1LL << 31), "%s: extended volume overflows int", who);
+  gauge->precision = precision;
+  gauge->stride = (int)(volEx / 2);
+  gauge->parity_offset = (int64_t)36 * gauge->stride;
+  gauge->data = nullptr;
+  const size_t bytes = mugiq_hip_extended_gauge_bytes(X, R, precision);
+  MUGIQ_CHECK_HIP(hipMalloc(&gauge->data, bytes));
+  MUGIQ_CHECK_HIP(hipMemset(gauge->data, 0, bytes));
+  return MUGIQ_HIP_SUCCESS;
+}
+
+int mugiq_hip_free_extended_gauge(MugiqHipGaugeField *gauge) {
+  if (gauge && gauge->data) {
+    MUGIQ_CHECK_HIP(hipFree(gauge->data));
+    gauge->data = nullptr;
+  }
+  return MUGIQ_HIP_SUCCESS;
+}
+
 int mugiq_hip_create_extended_gauge(const MugiqHipGaugeField *gauge, const void *const qdpLinks_h[4], int cpuPrecision,
                                     const MugiqHipComm *comm, void *stream) {
   const char *who = "createExtendedCudaGaugeField";

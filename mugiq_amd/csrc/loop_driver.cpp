@@ -78,6 +78,12 @@ struct MugiqHipLoop_s {
   std::vector<MugiqHipCoarseField> coarseVecs;
   MugiqHipTransfer transfer;
   void *fineStore = nullptr;  // prolonged eigenvectors, owned; NULL when only the fused prolong-contract is needed
+  // more than one coarse level (mg_env.nCoarseLevels > 1): the eigenvectors live on the coarsest level; upper[l] is the
+  // transfer between level l+1 and level l+2, levelVecs[l] the eigenvectors on level l+1 (levelVecs.back() = the input,
+  // levelVecs[0] = coarseVecs, what the finest transfer prolongs); levelStore[l] owns the intermediate fields of level l+1
+  std::vector<MugiqHipTransfer> upper;
+  std::vector<std::vector<MugiqHipCoarseField>> levelVecs;
+  std::vector<void *> levelStore;
   // ---- displacement scratch (Displace::auxDispVec and friends)
   // Scratch lives in a pool owned by the loop object: hipMalloc/hipFree of ~GB buffers per displacement entry cost
   // 10-100 ms and synchronise the device (measured), so buffers are recycled across entries and computes.
@@ -752,16 +758,26 @@ int mugiq_hip_loop_create(MugiqHipLoop **out, const MugiqHipLoopParam *p, const 
 }
 
 // Loop_Mugiq with eigsolve->useMGenv && eigsolve->computeCoarse (lib/loop_mugiq.cpp:42,482): the eigenvectors live on
-// the coarse grid and are prolonged with the MG transfer operator before they are contracted.
-int mugiq_hip_loop_create_coarse(MugiqHipLoop **out, const MugiqHipLoopParam *p, const MugiqHipCoarseField *coarseEvecs_h,
-                                 const double *eVals_sigma_h, int nEv, const MugiqHipTransfer *transfer, int fineFieldOrder,
-                                 const MugiqHipComm *comm, void *stream) {
+// the coarsest grid and are prolonged through the MG transfer operators before they are contracted
+// (prolongateEvec, lib/loop_mugiq.cpp:277-319: transfer[lev-1]->P for lev = nCoarseLevels .. 2, then transfer[0]->P).
+int mugiq_hip_loop_create_coarse_levels(MugiqHipLoop **out, const MugiqHipLoopParam *p, const MugiqHipCoarseField *coarseEvecs_h,
+                                        const double *eVals_sigma_h, int nEv, const MugiqHipTransfer *transfers_h, int nCoarseLevels,
+                                        int fineFieldOrder, const MugiqHipComm *comm, void *stream) {
   const char *who = "Loop_Mugiq(coarse)";
-  MUGIQ_REQUIRE(out && p && coarseEvecs_h && eVals_sigma_h && transfer, "%s: NULL argument", who);
+  MUGIQ_REQUIRE(out && p && coarseEvecs_h && eVals_sigma_h && transfers_h, "%s: NULL argument", who);
   MUGIQ_REQUIRE(nEv >= 1, "%s: nEv = %d must be >= 1", who, nEv);
+  MUGIQ_REQUIRE(nCoarseLevels >= 1 && nCoarseLevels <= 4, "%s: nCoarseLevels = %d must be in [1, 4] (QUDA_MAX_MG_LEVEL - 1)", who, nCoarseLevels);
   // the reference insists on FLOAT2 for the MG-coarse path (lib/loop_mugiq.cpp:283, lib/interface_mugiq.cpp:226-230)
   MUGIQ_REQUIRE(fineFieldOrder == 2, "%s: Vector prolongation requires fieldOrder = FLOAT2", who);
-  MUGIQ_REQUIRE(transfer->V && (transfer->precision == 4 || transfer->precision == 8), "%s: invalid transfer", who);
+  const MugiqHipTransfer *transfer = &transfers_h[0];
+  MUGIQ_REQUIRE(transfer->V && (transfer->precision == 4 || transfer->precision == 8), "%s: Transfer operator for finest level does not exist!", who);
+  for (int l = 1; l < nCoarseLevels; l++) {
+    MUGIQ_REQUIRE(transfers_h[l].V, "%s: Transfer operator for level %d does not exist!", who, l + 1);  // lib/loop_mugiq.cpp:309
+    MUGIQ_REQUIRE(transfers_h[l].precision == transfer->precision, "%s: transfer level %d differs in precision", who, l);
+    for (int d = 0; d < 4; d++)
+      MUGIQ_REQUIRE(transfers_h[l].X[d] * transfers_h[l - 1].geoBlockSize[d] == transfers_h[l - 1].X[d],
+                    "%s: transfer level %d: X[%d] = %d is not level %d's X / geo_block_size", who, l, d, transfers_h[l].X[d], l - 1);
+  }
   *out = nullptr;
   long long vol = 1;
   for (int d = 0; d < 4; d++) {
@@ -795,11 +811,47 @@ int mugiq_hip_loop_create_coarse(MugiqHipLoop **out, const MugiqHipLoopParam *p,
     return st;
   }
   lp->coarseMode = true;
-  lp->coarseVecs.assign(coarseEvecs_h, coarseEvecs_h + nEv);
   lp->transfer = *transfer;
   lp->fineStore = store;
+  // levelVecs[l] = eigenvectors on level l + 1; the input sits on the coarsest one, the others are owned temporaries
+  // (tmpCSF[1 .. nCoarseLevels-1] of the reference, allocated once instead of per eigenvector and call)
+  lp->levelVecs.resize(nCoarseLevels);
+  lp->levelStore.assign(nCoarseLevels, nullptr);
+  lp->levelVecs[nCoarseLevels - 1].assign(coarseEvecs_h, coarseEvecs_h + nEv);
+  for (int l = nCoarseLevels - 2; l >= 0; l--) {
+    const MugiqHipTransfer &T = transfers_h[l + 1];  // between level l+1 (finer side, dims T.X) and level l+2
+    lp->upper.insert(lp->upper.begin(), T);
+    MugiqHipCoarseField f{};
+    f.precision = T.precision;
+    f.nSpin = 2;
+    f.nColor = transfers_h[l].nVec;
+    long long v = 1;
+    for (int d = 0; d < 4; d++) {
+      f.X[d] = T.X[d];
+      v *= T.X[d];
+    }
+    f.volumeCB = (int)(v / 2);
+    f.stride = f.volumeCB;
+    f.parity_offset = (int64_t)2 * f.nColor * f.stride;
+    const size_t bytes = (size_t)2 * f.parity_offset * 2 * (size_t)T.precision;
+    if (hipMalloc(&lp->levelStore[l], bytes * (size_t)nEv) != hipSuccess) {
+      mugiq_hip_loop_destroy(lp);
+      return set_error(MUGIQ_HIP_ERROR_HIP, "%s: could not allocate the eigenvectors of coarse level %d", who, l + 1);
+    }
+    for (int n = 0; n < nEv; n++) {
+      f.data = static_cast<char *>(lp->levelStore[l]) + bytes * (size_t)n;
+      lp->levelVecs[l].push_back(f);
+    }
+  }
+  lp->coarseVecs = lp->levelVecs[0];
   *out = lp;
   return MUGIQ_HIP_SUCCESS;
+}
+
+int mugiq_hip_loop_create_coarse(MugiqHipLoop **out, const MugiqHipLoopParam *p, const MugiqHipCoarseField *coarseEvecs_h,
+                                 const double *eVals_sigma_h, int nEv, const MugiqHipTransfer *transfer, int fineFieldOrder,
+                                 const MugiqHipComm *comm, void *stream) {
+  return mugiq_hip_loop_create_coarse_levels(out, p, coarseEvecs_h, eVals_sigma_h, nEv, transfer, 1, fineFieldOrder, comm, stream);
 }
 
 int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
@@ -810,6 +862,14 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
   lp->phases.clear();
   lp->eventsUsed = 0;
   const auto tWall0 = std::chrono::steady_clock::now();
+  if (lp->coarseMode && lp->levelVecs.size() > 1) {
+    // coarsest level -> level 1 through the upper transfer operators (lib/loop_mugiq.cpp:306-311), all eigenvectors per launch
+    const int ph = phase_begin(lp, MUGIQ_HIP_PHASE_PROLONGATION, -1, lp->stream);
+    for (int l = (int)lp->levelVecs.size() - 1; l >= 1; l--)
+      if ((st = mugiq_hip_prolongate_coarse_batched(lp->levelVecs[l - 1].data(), lp->levelVecs[l].data(), lp->nEv, &lp->upper[l - 1], lp->stream)))
+        return st;
+    phase_end(lp, ph, lp->stream);
+  }
   if (lp->coarseMode && lp->fineStore) {
     // prolongateEvec for every eigenvector, once (the reference repeats it per displacement entry, lib/loop_mugiq.cpp:482)
     const int ph = phase_begin(lp, MUGIQ_HIP_PHASE_PROLONGATION, -1, lp->stream);
@@ -1086,6 +1146,8 @@ int mugiq_hip_loop_destroy(MugiqHipLoop *lp) {  // freeDataMemory, lib/loop_mugi
   if (lp->dataMom != lp->dataMom_h) free(lp->dataMom);
   free(lp->dataPos);
   if (lp->fineStore) (void)hipFree(lp->fineStore);
+  for (void *q : lp->levelStore)
+    if (q) (void)hipFree(q);
   for (auto &h : lp->halo) {
     if (h.evPacked) (void)hipEventDestroy(h.evPacked);
     if (h.evHalo) (void)hipEventDestroy(h.evHalo);

@@ -262,6 +262,101 @@ static int launch_prolong(const MugiqHipTransfer *T, const MugiqHipCoarseField *
 }
 
 
+// ---- coarse -> coarse levels of the hierarchy --------------------------------------------------------------------------
+// Loop_Mugiq::prolongateEvec walks the MG hierarchy from the coarsest level up (lib/loop_mugiq.cpp:306-311:
+// transfer[lev-1]->P(tmpCSF[lev-1], tmpCSF[lev]) for lev = nCoarseLevels .. 2) before the finest transfer (:314).  Both sides
+// of such a level are coarse fields with nSpin = 2 (the chirality survives every level: spin_block_size = 1 there), so
+//     out(x; s, c) = sum_{j < n_vec} V(x; s, c, j) * in(X(x); s, j),    c < nColor(out) = n_vec of the next finer level,
+// V = FieldOrderCB<Float, 2, nColor(out), n_vec, FLOAT2>: plane (s * nColor(out) + c) * n_vec + j.
+// The intermediate lattices are 256 x smaller than the fine one, so this is a plain kernel: lane = site (coalesced along
+// x_cb), blockIdx.y = output component, a lane carries kPcEvecs eigenvectors so that every V element it loads is used
+// kPcEvecs times; sums run over j in ascending order in the field precision.
+constexpr int kPcEvecs = 8;
+template <typename F> struct ProlongCoarseArgs {
+  const Cplx<F> *V;
+  int64_t Vpo;
+  int Vstride, NV, NCf;
+  int X[4], Xc[4], bs[4];
+  int volumeCB;
+  const void *const *in;  // device table: nVec coarser bodies, then nVec finer bodies
+  int64_t Ipo, Opo;
+  int Istride, Ostride, nVec;
+};
+
+template <typename F> __global__ __launch_bounds__(128) void prolong_coarse_kernel(ProlongCoarseArgs<F> a) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= 2 * a.volumeCB) return;
+  const int pty = tid / a.volumeCB, x_cb = tid - pty * a.volumeCB;
+  const int k = blockIdx.y, s = k / a.NCf;  // output component (s, c); the coarser field's spin is the same chirality
+  const int n0 = blockIdx.z * kPcEvecs;
+  int c[4], cc[4];
+  get_coords(c, x_cb, a.X, pty);
+#pragma unroll
+  for (int d = 0; d < 4; d++) cc[d] = c[d] / a.bs[d];
+  const int cpar = (cc[0] + cc[1] + cc[2] + cc[3]) & 1;
+  const int64_t coff = (int64_t)cpar * a.Ipo + (lex_index(cc, a.Xc) >> 1);
+  const Cplx<F> *inp[kPcEvecs];
+#pragma unroll
+  for (int i = 0; i < kPcEvecs; i++) {
+    const int n = n0 + i < a.nVec ? n0 + i : a.nVec - 1;
+    inp[i] = static_cast<const Cplx<F> *>(as_constant(a.in)[n]) + coff + (int64_t)(s * a.NV) * a.Istride;
+  }
+  Cplx<F> acc[kPcEvecs];
+#pragma unroll
+  for (int i = 0; i < kPcEvecs; i++) acc[i] = Cplx<F>{F(0), F(0)};
+  const Cplx<F> *vp = a.V + (int64_t)pty * a.Vpo + (int64_t)k * a.NV * a.Vstride + x_cb;
+  for (int j = 0; j < a.NV; j++) {
+    const Cplx<F> v = vp[(int64_t)j * a.Vstride];
+#pragma unroll
+    for (int i = 0; i < kPcEvecs; i++) {
+      typedef F vec2 __attribute__((ext_vector_type(2)));
+      const vec2 u = *as_global(reinterpret_cast<const vec2 *>(inp[i] + (int64_t)j * a.Istride));
+      cmadd(acc[i], v, Cplx<F>{u.x, u.y});
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kPcEvecs; i++)
+    if (n0 + i < a.nVec) {
+      Cplx<F> *o = static_cast<Cplx<F> *>(const_cast<void *>(as_constant(a.in)[a.nVec + n0 + i]));
+      o[(int64_t)pty * a.Opo + (int64_t)k * a.Ostride + x_cb] = acc[i];
+    }
+}
+
+template <typename F>
+static int launch_prolong_coarse(const MugiqHipCoarseField *out, const MugiqHipCoarseField *in, int nVec, const MugiqHipTransfer *T,
+                                 hipStream_t stream) {
+  std::vector<const void *> host(2 * (size_t)nVec);
+  for (int n = 0; n < nVec; n++) {
+    host[n] = in[n].data;
+    host[nVec + n] = out[n].data;
+  }
+  void *dev = nullptr;
+  int st = upload_table(&dev, host.data(), host.size() * sizeof(void *), stream);
+  if (st) return st;
+  ProlongCoarseArgs<F> a;
+  a.V = static_cast<const Cplx<F> *>(T->V);
+  a.Vpo = T->parity_offset;
+  a.Vstride = T->stride;
+  a.NV = T->nVec;
+  a.NCf = out[0].nColor;
+  for (int d = 0; d < 4; d++) {
+    a.X[d] = T->X[d];
+    a.bs[d] = T->geoBlockSize[d];
+    a.Xc[d] = T->X[d] / T->geoBlockSize[d];
+  }
+  a.volumeCB = out[0].volumeCB;
+  a.in = reinterpret_cast<const void *const *>(dev);
+  a.Ipo = in[0].parity_offset;
+  a.Istride = in[0].stride;
+  a.Opo = out[0].parity_offset;
+  a.Ostride = out[0].stride;
+  a.nVec = nVec;
+  const dim3 grid((2 * a.volumeCB + 127) / 128, 2 * a.NCf, (nVec + kPcEvecs - 1) / kPcEvecs);
+  hipLaunchKernelGGL((prolong_coarse_kernel<F>), grid, dim3(128), 0, stream, a);
+  MUGIQ_CHECK_HIP(hipGetLastError());
+  return MUGIQ_HIP_SUCCESS;
+}
+
 // ---- MG ultra-local loop through the coarse-grid outer product -----------------------------------------------------
 // With psi_n(x) = V(x) phi_n(X(x)) the weighted sum over the eigenvectors can be taken on the COARSE grid first:
 //     sum_n s_n psi_n(x) psi_n(x)^dagger = V(x) C(X) V(x)^dagger,     C(X) = sum_n s_n phi_n(X) phi_n(X)^dagger,
@@ -586,6 +681,41 @@ int mugiq_hip_prolongate_batched(const MugiqHipSpinorField *fine_h, const MugiqH
   if (p == 8 && o == 4) return launch_prolong<double, double, 4, true, false>(transfer, coarse_h, fine_h, nullptr, nullptr, nVec, s);
   if (p == 4 && o == 2) return launch_prolong<float, float, 2, true, false>(transfer, coarse_h, fine_h, nullptr, nullptr, nVec, s);
   return launch_prolong<float, float, 4, true, false>(transfer, coarse_h, fine_h, nullptr, nullptr, nVec, s);
+}
+
+int mugiq_hip_prolongate_coarse_batched(const MugiqHipCoarseField *out_h, const MugiqHipCoarseField *in_h, int nVec,
+                                        const MugiqHipTransfer *T, void *stream) {
+  const char *who = "prolongateEvec(coarse level)";
+  MUGIQ_REQUIRE(out_h && in_h && nVec >= 1, "%s: NULL / empty argument", who);
+  MUGIQ_REQUIRE(T && T->V, "%s: Transfer operator for this level does not exist!", who);  // lib/loop_mugiq.cpp:309
+  MUGIQ_REQUIRE(T->precision == 4 || T->precision == 8, "%s: transfer precision %d", who, T->precision);
+  MUGIQ_REQUIRE(T->nVec >= 1 && T->nVec <= 96, "%s: n_vec = %d must be in [1, 96]", who, T->nVec);
+  MUGIQ_REQUIRE(T->spinBlockSize == 1, "%s: spin_block_size = %d: a coarse level keeps both chiralities (1)", who, T->spinBlockSize);
+  const MugiqHipCoarseField &o = out_h[0], &i = in_h[0];
+  MUGIQ_REQUIRE(o.nSpin == 2 && i.nSpin == 2 && i.nColor == T->nVec && o.nColor >= 1 && o.nColor <= 96, "%s: fields must have nSpin 2; coarser nColor = n_vec = %d", who, T->nVec);
+  long long vol = 1, volc = 1;
+  for (int d = 0; d < 4; d++) {
+    MUGIQ_REQUIRE(T->X[d] > 0 && (T->X[d] & 1) == 0 && o.X[d] == T->X[d], "%s: finer lattice X[%d] = %d (field: %d) must be positive, even and equal", who, d, T->X[d], o.X[d]);
+    MUGIQ_REQUIRE(T->geoBlockSize[d] >= 1 && T->X[d] % T->geoBlockSize[d] == 0, "%s: geo_block_size[%d] = %d does not divide X = %d", who, d, T->geoBlockSize[d], T->X[d]);
+    const int xc = T->X[d] / T->geoBlockSize[d];
+    MUGIQ_REQUIRE((xc & 1) == 0 && i.X[d] == xc, "%s: coarser extent in dim %d must be even and equal X/block = %d (field: %d)", who, d, xc, i.X[d]);
+    vol *= T->X[d];
+    volc *= xc;
+  }
+  MUGIQ_REQUIRE(o.volumeCB == vol / 2 && i.volumeCB == volc / 2, "%s: volumeCB mismatch", who);
+  MUGIQ_REQUIRE(T->stride >= vol / 2 && T->parity_offset >= (int64_t)2 * o.nColor * T->nVec * T->stride, "%s: V stride / parity_offset too small", who);
+  for (int n = 0; n < nVec; n++) {
+    MUGIQ_REQUIRE(out_h[n].data && in_h[n].data && out_h[n].data != in_h[n].data, "%s: field %d is NULL or aliased", who, n);
+    MUGIQ_REQUIRE(out_h[n].precision == T->precision && in_h[n].precision == T->precision, "%s: field %d: precision differs from the transfer's", who, n);
+    MUGIQ_REQUIRE(out_h[n].stride == o.stride && out_h[n].parity_offset == o.parity_offset && out_h[n].nColor == o.nColor &&
+                      in_h[n].stride == i.stride && in_h[n].parity_offset == i.parity_offset && in_h[n].nColor == i.nColor,
+                  "%s: field %d differs in layout from field 0", who, n);
+  }
+  MUGIQ_REQUIRE(o.stride >= o.volumeCB && o.parity_offset >= (int64_t)2 * o.nColor * o.stride && i.stride >= i.volumeCB &&
+                    i.parity_offset >= (int64_t)2 * i.nColor * i.stride, "%s: field stride / parity_offset too small", who);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (T->precision == 8) return launch_prolong_coarse<double>(out_h, in_h, nVec, T, s);
+  return launch_prolong_coarse<float>(out_h, in_h, nVec, T, s);
 }
 
 int mugiq_hip_prolongate_contract_batched(void *loopData_d, int loopPrecision, const MugiqHipCoarseField *coarse_h,

@@ -212,20 +212,32 @@ class CoarseField:
         self.data.copy_(torch.from_numpy(buf))
         return self
 
+    def get_logical(self):
+        """[2, volCB_c, 2, n_vec]"""
+        p = np.arange(2).reshape(2, 1, 1, 1)
+        x = np.arange(self.volumeCB).reshape(1, -1, 1, 1)
+        s = np.arange(2).reshape(1, 1, 2, 1)
+        c = np.arange(self.n_vec).reshape(1, 1, 1, -1)
+        return self.data.cpu().numpy()[p * self.parity_offset + (s * self.n_vec + c) * self.stride + x]
+
 
 class Transfer:
-    """One level of QUDA's Transfer as the hot path sees it: the block-orthonormal null vectors V on the fine grid
-    (packed vector index), the aggregate size and the spin blocking."""
+    """One level of QUDA's Transfer as the hot path sees it: the block-orthonormal null vectors V on the finer grid of
+    the level (packed vector index), the aggregate size and the spin blocking.  Finest level: the finer side is the
+    fine lattice (4 spins x 3 colours, spin_block_size 2).  A coarse -> coarse level: fine_spin = 2, fine_color = n_vec of
+    the next finer level, spin_block_size = 1."""
 
-    def __init__(self, X, n_vec=24, geo_block_size=(4, 4, 4, 4), spin_block_size=2, precision=8, pad=0, device="cuda"):
+    def __init__(self, X, n_vec=24, geo_block_size=(4, 4, 4, 4), spin_block_size=2, precision=8, pad=0, device="cuda",
+                 fine_spin=4, fine_color=3):
         self.X = tuple(int(x) for x in X)
         self.n_vec = int(n_vec)
         self.geo_block_size = tuple(int(b) for b in geo_block_size)
         self.spin_block_size = int(spin_block_size)
+        self.fine_spin, self.fine_color = int(fine_spin), int(fine_color)
         self.precision = int(precision)
         self.volumeCB = int(np.prod(self.X)) // 2
         self.stride = self.volumeCB + int(pad)
-        self.parity_offset = 12 * self.n_vec * self.stride
+        self.parity_offset = self.fine_spin * self.fine_color * self.n_vec * self.stride
         self.device = torch.device(device)
         self.V = torch.zeros(2 * self.parity_offset, dtype=_cdtype(precision), device=self.device)
         self.Xc = tuple(self.X[d] // self.geo_block_size[d] for d in range(4))
@@ -241,18 +253,26 @@ class Transfer:
         return d
 
     def set_logical(self, V):
-        """V: [2, volCB, 4, 3, n_vec]"""
+        """V: [2, volCB, fine_spin, fine_color, n_vec]"""
         V = np.asarray(V)
-        assert V.shape == (2, self.volumeCB, 4, 3, self.n_vec)
+        ns, nc = self.fine_spin, self.fine_color
+        assert V.shape == (2, self.volumeCB, ns, nc, self.n_vec)
         p = np.arange(2).reshape(2, 1, 1, 1, 1)
         x = np.arange(self.volumeCB).reshape(1, -1, 1, 1, 1)
-        s = np.arange(4).reshape(1, 1, 4, 1, 1)
-        c = np.arange(3).reshape(1, 1, 1, 3, 1)
+        s = np.arange(ns).reshape(1, 1, ns, 1, 1)
+        c = np.arange(nc).reshape(1, 1, 1, nc, 1)
         j = np.arange(self.n_vec).reshape(1, 1, 1, 1, -1)
         buf = np.zeros(2 * self.parity_offset, dtype=_np_cdtype(self.precision))
-        buf[p * self.parity_offset + ((3 * s + c) * self.n_vec + j) * self.stride + x] = V.astype(buf.dtype)
+        buf[p * self.parity_offset + ((nc * s + c) * self.n_vec + j) * self.stride + x] = V.astype(buf.dtype)
         self.V.copy_(torch.from_numpy(buf))
         return self
+
+
+def transfer_desc_array(transfers):
+    arr = (_lib.TransferDesc * len(transfers))()
+    for i, t in enumerate(transfers):
+        arr[i] = t.desc()
+    return arr
 
 
 def coarse_desc_array(fields):

@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from .comm import device_bytes
-from .fields import GaugeField, desc_array, coarse_desc_array
+from .fields import GaugeField, desc_array, coarse_desc_array, transfer_desc_array
 
 LOOP_CALC_TYPE_BLAS, LOOP_CALC_TYPE_OPT_KERNEL, LOOP_CALC_TYPE_BASIC_KERNEL = 0, 1, 2   # include/enum_mugiq.h:35-41
 
@@ -120,7 +120,8 @@ class Loop_Mugiq:
     `eVecs` / `eVals_sigma` are what the reference reads out of Eigsolve_Mugiq (lib/loop_mugiq.cpp:442,479)."""
 
     def __init__(self, loopParams, eVecs, eVals_sigma, comm=None, transfer=None):
-        """`transfer` given: eVecs are CoarseField eigenvectors (eigsolve->computeCoarse) prolonged with it."""
+        """`transfer` given: eVecs are CoarseField eigenvectors (eigsolve->computeCoarse) prolonged with it; a list
+        [finest, level 1 -> 2, ...] for an MG hierarchy with several coarse levels (eVecs on the coarsest one)."""
         lib = _lib.load()
         self._keep = []
         self._params, self._transfer = loopParams, transfer
@@ -162,6 +163,12 @@ class Loop_Mugiq:
         if transfer is None:
             _lib.check(lib.mugiq_hip_loop_create(ctypes.byref(self._handle), ctypes.byref(p), desc_array(self.eVecs), sg,
                                                  len(self.eVecs), ctypes.byref(c) if c is not None else None, stream))
+        elif isinstance(transfer, (list, tuple)):
+            ts = transfer_desc_array(transfer)
+            self._keep += [ts, list(transfer)]
+            _lib.check(lib.mugiq_hip_loop_create_coarse_levels(ctypes.byref(self._handle), ctypes.byref(p), coarse_desc_array(self.eVecs),
+                                                               sg, len(self.eVecs), ts, len(transfer), 2,
+                                                               ctypes.byref(c) if c is not None else None, stream))
         else:
             t = transfer.desc()
             self._keep += [t, transfer]

@@ -197,6 +197,16 @@ def prolongateEvecs(fineEvecs, coarseEvecs, transfer):
                                                         ctypes.byref(t), _stream()))
 
 
+def prolongateCoarseEvecs(finerEvecs, coarserEvecs, transfer):
+    """One coarse -> coarse level, mg_env.transfer[lev-1]->P(tmpCSF[lev-1], tmpCSF[lev]) for all eigenvectors in one launch
+    (lib/loop_mugiq.cpp:306-311)."""
+    n = len(finerEvecs)
+    assert len(coarserEvecs) == n and n >= 1
+    t = transfer.desc()
+    _lib.check(_lib.load().mugiq_hip_prolongate_coarse_batched(coarse_desc_array(finerEvecs), coarse_desc_array(coarserEvecs), n,
+                                                               ctypes.byref(t), _stream()))
+
+
 def prolongateContractBatched(loopData_d, coarseEvecs, sigmas, transfer):
     """loopData += sum_n (1/sigma_n) (P c_n)^dag G (P c_n) without writing the fine vectors (MG ultra-local loop)."""
     n = len(coarseEvecs)

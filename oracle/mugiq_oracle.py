@@ -580,13 +580,15 @@ def fine_to_coarse_map(X, geo_bs):
 
 
 def prolongate(coarse, V, X, geo_bs=(4, 4, 4, 4), spin_bs=2):
-    """Transfer::P for one level: fine[2, volCB, 4, 3] from coarse[2, volCB_c, 4/spin_bs, n_vec]."""
+    """Transfer::P for one level: finer[2, volCB, nSpin_f, nColor_f] from coarse[2, volCB_c, nSpin_f/spin_bs, n_vec] with
+    V[2, volCB, nSpin_f, nColor_f, n_vec].  Finest level: nSpin_f 4, nColor_f 3, spin_bs 2.  Coarse -> coarse levels
+    (transfer[lev-1]->P in lib/loop_mugiq.cpp:310): nSpin_f 2, nColor_f = n_vec of the finer level, spin_bs 1."""
     nvec = V.shape[-1]
     cp, cx = fine_to_coarse_map(X, geo_bs)
     out = np.zeros(V.shape[:4], dtype=V.dtype)
     for pty in range(2):
-        phi = coarse[cp[pty], cx[pty]]                       # [volCB, 2, n_vec]
-        for s in range(4):
+        phi = coarse[cp[pty], cx[pty]]                       # [volCB, nSpin_c, n_vec]
+        for s in range(V.shape[2]):
             for j in range(nvec):                            # rotateFineColor: j in order
                 out[pty, :, s, :] += V[pty, :, s, :, j] * phi[:, s // spin_bs, j, None]
     return out
@@ -619,3 +621,13 @@ def nullvec_to_native(V, stride=None, parity_offset=None):
                 for j in range(nvec):
                     buf[p * parity_offset + ((3 * s + c) * nvec + j) * stride + x] = V[p, :, s, c, j]
     return buf
+
+
+def prolongate_levels(coarsest, Vs, Xs, geo_bss):
+    """Loop_Mugiq::prolongateEvec for nCoarseLevels = len(Vs) (lib/loop_mugiq.cpp:306-314): Vs[0] / Xs[0] / geo_bss[0] belong
+    to the finest transfer (spin_bs 2), Vs[l], l >= 1, to the transfer between level l and level l+1 (spin_bs 1, lattice
+    Xs[l] = Xs[l-1] / geo_bss[l-1]); `coarsest` lives on level len(Vs)."""
+    v = coarsest
+    for l in range(len(Vs) - 1, 0, -1):
+        v = prolongate(v, Vs[l], Xs[l], geo_bss[l], 1)       # transfer[lev-1]->P(tmpCSF[lev-1], tmpCSF[lev])
+    return prolongate(v, Vs[0], Xs[0], geo_bss[0], 2)        # transfer[0]->P(fineEvec, tmpCSF[1])

@@ -29,3 +29,24 @@ def hip():
     """The product bindings, built in-tree. GPU tests fail loudly if the HIP library is missing."""
     import mugiq_amd
     return mugiq_amd
+
+
+_MAXIMA = {}
+
+
+@pytest.fixture(scope="session")
+def record_max():
+    """record_max(name, value): keep the largest `value` seen under `name` over the session; written to
+    gpurun_out/parity_maxima.json at the end (the measured parity maxima quoted in DESIGN.md section 2)."""
+    def rec(name, value):
+        _MAXIMA[name] = max(float(value), _MAXIMA.get(name, 0.0))
+    return rec
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _MAXIMA:
+        import json
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_maxima.json"), "w") as f:
+            json.dump(dict(sorted(_MAXIMA.items())), f, indent=1)

@@ -97,20 +97,18 @@ int main(int argc, char **argv) {
     eVecs[n] = f;
     sigma[n] = 0.01 + 0.002 * n;
   }
-  // unit gauge (configs[0]), single domain: R = 0, built through Displace's setup path from QDP-ordered host links
-  GaugeField g{};
+  // unit gauge (configs[0]) handed over the way tests/loop.cpp:902-918 does: host links in QDP order in loopParams.gauge[4]
+  // + the gauge parameters; Loop_Mugiq builds the extended device field from them (Displace's setup path)
   std::vector<double> qdp((size_t)V * 18, 0.0);
   for (int s = 0; s < V; s++) qdp[(size_t)s * 18 + 0] = qdp[(size_t)s * 18 + 8] = qdp[(size_t)s * 18 + 16] = 1.0;
-  const void *links[4] = {qdp.data(), qdp.data(), qdp.data(), qdp.data()};
-  if (lp.doNonLocal == MUGIQ_BOOL_TRUE) {
-    int R[4] = {0, 0, 0, 0};
-    g.precision = 8; g.stride = vcb; g.parity_offset = (int64_t)36 * vcb;
-    for (int d = 0; d < 4; d++) { g.X[d] = X[d]; g.R[d] = 0; }
-    HIPCHK(hipMalloc(&g.data, mugiq_hip_extended_gauge_bytes(X, R, 8)));
-    try { mugiq_hip::check(mugiq_hip_create_extended_gauge(&g, links, 8, nullptr, nullptr)); }
-    catch (const Error &e) { fprintf(stderr, "%s\n", e.what()); return 1; }
-    lp.gauge = &g;
+  GaugeParam gp{};
+  for (int d = 0; d < 4; d++) {
+    gp.X[d] = X[d];
+    lp.gauge[d] = qdp.data();
   }
+  gp.cpu_prec = 8;
+  gp.cuda_prec = 8;
+  lp.gauge_param = &gp;
 
   int rc = 0;
   try {
@@ -148,7 +146,6 @@ int main(int argc, char **argv) {
     rc = 1;
   }
   for (void *p : dptr) (void)hipFree(p);
-  if (g.data) (void)hipFree(g.data);
   printf(rc == 0 ? "LOOP TEST PASSED\n" : "LOOP TEST FAILED\n");
   return rc;
 }

@@ -36,6 +36,28 @@ def test_library_exports_every_declared_symbol(hip, lib):
     assert set(hip._lib.SIGNATURES) == declared
 
 
+def test_quda_adapter_uses_only_declared_entry_points_and_descriptor_members(hip):
+    """include/mugiq_hip_quda_adapter.hpp cannot be compiled here (it needs QUDA's and MuGiq's headers); at least every C-ABI
+    entry point it calls is declared + exported, every descriptor member it fills exists in the ctypes mirror of the structs,
+    and it defines the reference's operator names and both computeLoop signatures."""
+    src = open(os.path.join(ROOT, "include", "mugiq_hip_quda_adapter.hpp")).read()
+    code = re.sub(r"//.*", "", src)
+    called = set(re.findall(r"\b(mugiq_hip_[a-z0-9_]+)\s*\(", code)) - {"mugiq_hip_adapter"}
+    assert called and called <= set(hip._lib.SIGNATURES), called - set(hip._lib.SIGNATURES)
+    members = {"MugiqHipSpinorField": hip._lib.SpinorDesc, "MugiqHipGaugeField": hip._lib.GaugeDesc,
+               "MugiqHipCoarseField": hip._lib.CoarseDesc, "MugiqHipTransfer": hip._lib.TransferDesc}
+    for m in re.finditer(r"inline (MugiqHip\w+) describe\w*\([^)]*\) \{(.*?)\n\}", code, flags=re.S):
+        fields = {f[0] for f in members[m.group(1)]._fields_}
+        var = re.search(r"%s (\w+)\{\};" % m.group(1), m.group(2)).group(1)
+        used = set(re.findall(r"\b%s\.(\w+)" % var, m.group(2)))
+        assert used and used <= fields, (m.group(1), used - fields)
+    for name in ("copyGammaCoeffStructToSymbol", "copyGammaMapStructToSymbol", "createPhaseMatrixGPU", "performLoopContraction",
+                 "convertIdxOrder_mapGamma", "performCovariantDisplacementVector"):           # include/loop_mugiq.h:280-311, displace.h:109-111
+        assert re.search(r"\bvoid %s\(" % name, code), name
+    assert "void computeLoop(MugiqLoopParam loopParams, Eigsolve_Mugiq *eigsolve)" in code            # lib/interface_mugiq.cpp:158
+    assert re.search(r"void computeLoop\(QudaMultigridParam mgParams, QudaEigParam QudaEigParams, MugiqLoopParam loopParams, MuGiqBool computeCoarse, MuGiqBool useMG\)", code)
+
+
 def test_version_and_device_count(lib):
     assert lib.mugiq_hip_version() == 100
     assert lib.mugiq_hip_device_count() >= 0

@@ -451,6 +451,32 @@ def test_prolongator_matches_oracle(hip, prec, order, X, bs, nvec, nev):
         assert rel_err(ff[n].get_logical(), exp) < (1e-14 if prec == 8 else 2e-6), n
 
 
+@pytest.mark.parametrize("prec", [8, 4])
+@pytest.mark.parametrize("X,bs,ncf,nvec,nev,pad", [((4, 4, 4, 8), (2, 2, 2, 2), 6, 4, 11, 0), ((8, 4, 4, 4), (2, 1, 2, 2), 24, 32, 3, 5),
+                                                   ((4, 4, 4, 4), (1, 1, 1, 1), 3, 3, 9, 0), ((12, 4, 4, 4), (3, 2, 2, 2), 8, 24, 17, 2)])
+def test_coarse_to_coarse_prolongator_matches_oracle(hip, prec, X, bs, ncf, nvec, nev, pad):
+    """One coarse -> coarse level (transfer[lev-1]->P, lib/loop_mugiq.cpp:310): nSpin 2 on both sides, spin_block_size 1;
+    eigenvector counts that are not multiples of the per-lane batch, padded strides."""
+    rng = np.random.default_rng(5150)
+    cdt = _np_c(prec)
+    vcb = int(np.prod(X)) // 2
+    Xc = [X[d] // bs[d] for d in range(4)]
+    vcbc = int(np.prod(Xc)) // 2
+    V = ((rng.standard_normal((2, vcb, 2, ncf, nvec)) + 1j * rng.standard_normal((2, vcb, 2, ncf, nvec))) / np.sqrt(2.0 * ncf * nvec)).astype(cdt)
+    phis = [(rng.standard_normal((2, vcbc, 2, nvec)) + 1j * rng.standard_normal((2, vcbc, 2, nvec))).astype(cdt) for _ in range(nev)]
+    T = hip.Transfer(X, nvec, bs, 1, prec, pad=pad, fine_spin=2, fine_color=ncf).set_logical(V)
+    cin = [hip.CoarseField(Xc, nvec, prec, pad=pad).set_logical(p) for p in phis]
+    cout = [hip.CoarseField(X, ncf, prec, pad=pad) for _ in range(nev)]
+    hip.prolongateCoarseEvecs(cout, cin, T)
+    for n in range(nev):
+        exp = orc.prolongate(phis[n].astype(np.complex128), V.astype(np.complex128), X, bs, 1)
+        assert rel_err(cout[n].get_logical(), exp) < (1e-14 if prec == 8 else 2e-6), n
+    with pytest.raises(hip.MugiqHipError):                                     # a finest-level transfer is not a coarse level
+        hip.prolongateCoarseEvecs(cout, cin, hip.Transfer(X, nvec, bs, 2, prec, fine_spin=2, fine_color=ncf))
+    with pytest.raises(hip.MugiqHipError):                                     # colour count of the coarser side != n_vec
+        hip.prolongateCoarseEvecs(cout, [hip.CoarseField(Xc, nvec + 1, prec) for _ in range(nev)], T)
+
+
 @pytest.mark.parametrize("plan", ["coarse", "direct"])
 @pytest.mark.parametrize("prec,lprec", [(8, 8), (4, 4), (4, 8)])
 @pytest.mark.parametrize("X,bs,nvec,nev", [((8, 8, 8, 8), (4, 4, 4, 4), 24, 37), ((4, 4, 4, 6), (2, 2, 2, 1), 3, 2),
@@ -690,3 +716,126 @@ def test_reflected_entry_with_ghost_layers_matches_single_domain(hip, dim):
                 dst = torch.zeros(16 * Vl, dtype=torch.complex128, device="cuda")
                 hip.reflectDisplacedLoop(dst, src[r], l, dim, dst_sign, k, comm, packed[ranks[1 - i]])   # 2 ranks: both neighbours are the other one
                 assert rel_err(dst.cpu().numpy(), local(ref_all[k - 1], r)) < 1e-13, (name, k, dst_sign, r)
+
+
+# ---- full-size property tests of the remaining BASELINE.json configurations ---------------------------------------
+def _device_evecs(hip, X, nev, prec, order, seed):
+    """N_ev unit-norm Gaussian eigenvectors generated on the device, one allocation; returns (fields, ||v_n||^2 in fp64
+    of the values actually stored)."""
+    vcb = int(np.prod(X)) // 2
+    per = 24 * vcb
+    cdt = torch.complex128 if prec == 8 else torch.complex64
+    big = torch.empty(nev * per, dtype=cdt, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    f, n2 = [], []
+    for n in range(nev):
+        w = torch.complex(torch.randn(per, dtype=torch.float64, device="cuda", generator=g),
+                          torch.randn(per, dtype=torch.float64, device="cuda", generator=g))
+        w /= torch.linalg.vector_norm(w)
+        v = big[n * per:(n + 1) * per]
+        v.copy_(w.to(cdt))
+        n2.append(float(torch.sum(v.real.double() ** 2 + v.imag.double() ** 2).item()))
+        f.append(hip.SpinorField(X, prec, order, data=v))
+        del w
+    return big, f, np.array(n2)
+
+
+def test_full_size_cfg3_mixed_precision_and_projection_properties(hip, record_max):
+    """BASELINE.json configs[3] at its per-GPU size: 64x64x32x16, fp32 FLOAT4 eigenvectors, N_ev = 600 (121 GB), fp32 and
+    mixed-precision loops, momentum projection onto p^2 <= 9.  Size-independent properties:
+      * Gamma = 1: sum_x L(x) = sum_n ||v_n||^2 / sigma_n -- mixed precision accumulates the fp32 inputs in fp64, so it equals
+        the fp64 evaluation on the rounded inputs to fp64 rounding; the fp32 loop agrees to north_star's 1e-5;
+      * mixed == fp32 loop to 1e-5 on every element (relative to the largest);
+      * the separable projection (reorder + x sum fused, then y, z) == the dense phase-matrix product of the reference's
+        formulation (lib/loop_mugiq.cpp:343-378), and its p = 0 row == the plain spatial sum."""
+    torch.cuda.empty_cache()
+    X, nev = (64, 64, 32, 16), 600
+    V = int(np.prod(X))
+    big, f, n2 = _device_evecs(hip, X, nev, 4, 4, 2718)
+    sg = sigmas(nev)
+    inv = 1.0 / np.float32(sg).astype(np.float64)              # the kernel divides by sigma cast to Float (contract_util.cuh:130-134)
+    loop64 = torch.zeros(16 * V, dtype=torch.complex128, device="cuda")
+    hip.performLoopContractionBatched(loop64, f, f, sg)         # complex128 loops over fp32 fields = mixed mode
+    expect = float(np.sum(n2 * inv))
+    got = loop64[:V].sum().item()
+    record_max("cfg3_full_size_mixed_gamma1_sum_rel", abs(got - expect) / expect)
+    assert abs(got - expect) < 1e-11 * expect and torch.max(torch.abs(loop64[:V].imag)).item() == 0.0
+    loop32 = torch.zeros(16 * V, dtype=torch.complex64, device="cuda")
+    hip.performLoopContractionBatched(loop32, f, f, sg)
+    e32 = (torch.max(torch.abs(loop32.to(torch.complex128) - loop64)) / torch.max(torch.abs(loop64))).item()
+    record_max("cfg3_full_size_fp32_vs_mixed", e32)
+    assert e32 < 1e-5
+    del big, f, loop32
+    torch.cuda.empty_cache()
+    # projection of the mixed-precision loop buffer: separable (one pass over the even-odd buffer) vs dense (reorder + product)
+    moms = momenta_p2_le(9)
+    Nmom, locT, locV3 = len(moms), X[3], X[0] * X[1] * X[2]
+    sep = torch.zeros(16 * locT * Nmom, dtype=torch.complex128, device="cuda")
+    hip.convertAndProject(sep, loop64, 16, 1, moms, -1, X, X)
+    mp_ = torch.zeros(16 * V, dtype=torch.complex128, device="cuda")
+    hip.convertIdxOrder_mapGamma(mp_, loop64, 16, 1, 2, V // 2, X)
+    ph = torch.zeros(locV3 * Nmom, dtype=torch.complex128, device="cuda")
+    hip.createPhaseMatrixGPU(ph, moms, locV3, Nmom, -1, X, X)
+    dense = torch.zeros_like(sep)
+    hip.momentumProjection(dense, mp_, ph, locT, 16, locV3, Nmom)
+    e = (torch.max(torch.abs(sep - dense)) / torch.max(torch.abs(dense))).item()
+    record_max("cfg3_full_size_separable_vs_dense", e)
+    assert e < 1e-12
+    i0 = moms.index((0, 0, 0))
+    # dataMom index t + locT*ig + locT*16*im; the reordered buffer is [v3][nData][t] with the G -> g5 G map applied
+    p0 = sep.view(Nmom, 16, locT)[i0]
+    plain = mp_.view(locV3, 16, locT).sum(0)
+    assert (torch.max(torch.abs(p0 - plain)) / torch.max(torch.abs(plain))).item() < 1e-12
+
+
+def test_full_size_cfg4_mg_plans_agree(hip, monkeypatch, record_max):
+    """BASELINE.json configs[4] at full size: 32^4 fp64, 4^4 aggregates, n_vec = 24, N_ev = 200 coarse eigenvectors.
+    The three routes to the MG ultra-local loop agree: coarse-grid plan (outer product on the coarse grid + one congruence
+    per fine site) == direct plan (prolong + contract per eigenvector, fused) == prolongateEvecs then the ordinary batched
+    contraction (the reference's sequence, lib/loop_mugiq.cpp:482,501-502)."""
+    torch.cuda.empty_cache()
+    X, bs, nvec, nev = (32, 32, 32, 32), (4, 4, 4, 4), 24, 200
+    V = int(np.prod(X))
+    T = hip.Transfer(X, nvec, bs, 2, 8)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    T.V.copy_(torch.complex(torch.randn(T.V.numel(), dtype=torch.float64, device="cuda", generator=g),
+                            torch.randn(T.V.numel(), dtype=torch.float64, device="cuda", generator=g)) / np.sqrt(24.0 * nvec))
+    cf = []
+    for n in range(nev):
+        c = hip.CoarseField(T.Xc, nvec, 8)
+        c.data.copy_(torch.complex(torch.randn(c.data.numel(), dtype=torch.float64, device="cuda", generator=g),
+                                   torch.randn(c.data.numel(), dtype=torch.float64, device="cuda", generator=g)))
+        cf.append(c)
+    sg = sigmas(nev)
+    out = {}
+    for plan in ("coarse", "direct"):
+        if plan == "direct":
+            monkeypatch.setenv("MUGIQ_HIP_MG_PLAN", "direct")
+        else:
+            monkeypatch.delenv("MUGIQ_HIP_MG_PLAN", raising=False)
+        out[plan] = torch.zeros(16 * V, dtype=torch.complex128, device="cuda")
+        hip.prolongateContractBatched(out[plan], cf, sg, T)
+    monkeypatch.delenv("MUGIQ_HIP_MG_PLAN", raising=False)
+    big = torch.empty(nev * 24 * (V // 2), dtype=torch.complex128, device="cuda")
+    ff = [hip.SpinorField(X, 8, 2, data=big[n * 24 * (V // 2):(n + 1) * 24 * (V // 2)]) for n in range(nev)]
+    hip.prolongateEvecs(ff, cf, T)
+    out["separate"] = torch.zeros(16 * V, dtype=torch.complex128, device="cuda")
+    hip.performLoopContractionBatched(out["separate"], ff, ff, sg)
+    scale = torch.max(torch.abs(out["separate"])).item()
+    for a, b in (("coarse", "direct"), ("coarse", "separate"), ("direct", "separate")):
+        e = torch.max(torch.abs(out[a] - out[b])).item() / scale
+        record_max("cfg4_full_size_%s_vs_%s" % (a, b), e)
+        assert e < 1e-12, (a, b, e)
+    # Gamma = 1 slot: sum_x L(x) = sum_n ||P c_n||^2 / sigma_n with the norms taken from the prolonged vectors
+    n2 = np.array([float(torch.sum(f.data.real ** 2 + f.data.imag ** 2).item()) for f in ff])
+    expect = float(np.sum(n2 / sg))
+    got = out["coarse"][:V].sum().item()
+    assert abs(got - expect) < 1e-11 * abs(expect)
+    # and through the driver (Loop_Mugiq with a transfer operator, no displacement entries -> fused route, fine vectors never stored)
+    del big, ff
+    torch.cuda.empty_cache()
+    loop = hip.Loop_Mugiq(hip.MugiqLoopParam(), cf, sg, transfer=T)
+    loop.computeCoarseLoop()
+    e = torch.max(torch.abs(loop.dataPos_d - out["coarse"])).item() / scale
+    assert e < 1e-13
+    loop.close()

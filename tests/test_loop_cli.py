@@ -86,7 +86,7 @@ def test_command_line_run_matches_oracle(hip, tmp_path, capsys, prec, calc):
     names = ["disp_0", "disp_+z_1", "disp_+z_2", "disp_-x_3", "disp_-t_1", "disp_-t_2"]
     fid = h5.open(str(out))
     scale = np.abs(ref).max()
-    tol = 1e-12 if prec == "double" else 2e-5
+    tol = 1e-12 if prec == "double" else 1e-5
     for im, p in enumerate(moms):
         for iL, dn in enumerate(names):
             for ig in range(16):

@@ -369,6 +369,53 @@ def test_prolongator_block_structure_and_adjoint_identity():
     assert vb[0 * (12 * nvec * vcb) + ((3 * 2 + 1) * nvec + 4) * vcb + 5] == V[0, 5, 2, 1, 4]
 
 
+def _mg_hierarchy(rng, X0, bss, nvecs):
+    """Synthetic 1 + len(bss) level hierarchy: Vs[l], lattice Xs[l] (finer side), block sizes, and the coarsest lattice."""
+    Xs, Vs = [tuple(X0)], []
+    for l, (bs, nv) in enumerate(zip(bss, nvecs)):
+        X = Xs[l]
+        vcb = int(np.prod(X)) // 2
+        ns, nc = (4, 3) if l == 0 else (2, nvecs[l - 1])
+        Vs.append((rng.standard_normal((2, vcb, ns, nc, nv)) + 1j * rng.standard_normal((2, vcb, ns, nc, nv))) / np.sqrt(ns * nc * nv))
+        Xs.append(tuple(X[d] // bs[d] for d in range(4)))
+    return Vs, Xs[:-1], Xs[-1]
+
+
+def test_multilevel_prolongation_is_the_composition_of_the_levels():
+    """prolongateEvec with nCoarseLevels = 2 (lib/loop_mugiq.cpp:306-314): P_0 P_1 phi.  Checks: linearity; chirality is
+    preserved through BOTH levels (spin_bs 2 then 1: upper spins of the fine vector see only chirality 0 of the coarsest
+    one); locality (a coarsest-site delta prolongs onto exactly the fine sites of its aggregate of aggregates); and the
+    explicit double sum over (j1, j2) at a few sites."""
+    rng = np.random.default_rng(31)
+    X0, bss, nvecs = (8, 8, 8, 16), [(2, 2, 2, 2), (2, 2, 2, 4)], [4, 3]
+    Vs, Xs, Xcc = _mg_hierarchy(rng, X0, bss, nvecs)
+    vcbcc = int(np.prod(Xcc)) // 2
+    phi = rng.standard_normal((2, vcbcc, 2, nvecs[1])) + 1j * rng.standard_normal((2, vcbcc, 2, nvecs[1]))
+    chi = rng.standard_normal(phi.shape) + 1j * rng.standard_normal(phi.shape)
+    psi = orc.prolongate_levels(phi, Vs, Xs, bss)
+    assert psi.shape == (2, int(np.prod(X0)) // 2, 4, 3)
+    assert rel_err(orc.prolongate_levels(2j * phi + chi, Vs, Xs, bss), 2j * psi + orc.prolongate_levels(chi, Vs, Xs, bss)) < 1e-13
+    only0 = phi.copy()
+    only0[:, :, 1] = 0
+    p0 = orc.prolongate_levels(only0, Vs, Xs, bss)
+    assert np.all(p0[:, :, 2:] == 0) and rel_err(p0[:, :, :2], psi[:, :, :2]) < 1e-14
+    # explicit double sum at fine sites: psi(x; s, c) = sum_j1 V0(x; s,c,j1) sum_j2 V1(X1(x); s/2, j1, j2) phi(X2(X1(x)); s/2, j2)
+    cp0, cx0 = orc.fine_to_coarse_map(Xs[0], bss[0])
+    cp1, cx1 = orc.fine_to_coarse_map(Xs[1], bss[1])
+    for pty, x in ((0, 0), (1, 17), (0, 1234), (1, int(np.prod(X0)) // 2 - 1)):
+        p1, x1 = cp0[pty, x], cx0[pty, x]
+        p2, x2 = cp1[p1, x1], cx1[p1, x1]
+        for s in range(4):
+            mid = np.einsum("jk,k->j", Vs[1][p1, x1, s // 2], phi[p2, x2, s // 2])
+            exp = Vs[0][pty, x, s] @ mid
+            assert np.allclose(psi[pty, x, s], exp, rtol=1e-12, atol=1e-14)
+    one = np.zeros_like(phi)
+    one[1, 2, 0, 1] = 1.0
+    sup = np.abs(orc.prolongate_levels(one, Vs, Xs, bss)).sum(axis=(2, 3)) > 0
+    want = (cp1[cp0, cx0] == 1) & (cx1[cp0, cx0] == 2)
+    assert np.array_equal(sup, want) and sup.sum() == int(np.prod(bss[0])) * int(np.prod(bss[1]))
+
+
 # ---- (10) reflection: a minus-direction loop is the shifted conjugate of the plus-direction one -----------
 def gamma_dagger_sign():
     """G(n)^dagger = eta_n G(n) for G(n) = g1^n0 g2^n1 g3^n2 g4^n3 (Hermitian, anticommuting factors):
