@@ -34,6 +34,7 @@ int stream_scratch(void **ptr, size_t bytes, hipStream_t stream);
 int stream_workspace(void **ptr, size_t bytes, hipStream_t stream);
 int upload_table(void **dev, const void *host, size_t bytes, hipStream_t stream);
 int release_stream_scratch(hipStream_t stream);
+size_t eo_dft_x_lds_bytes(int precision, const int localL[4], int nPx, int *redOffsetElems);  // momproj.hip
 int fill_identity_links(const MugiqHipSpinorField *f, hipStream_t stream);  // displace.hip
 
 // ---- address spaces ---------------------------------------------------------------------------------------------

@@ -496,7 +496,7 @@ static int momentum_projection(MugiqHipLoop *lp) {
     std::vector<int> px;  // distinct p_x: the phase rows of the x step
     for (int n = 0; n < lp->Nmom; n++)
       if (std::find(px.begin(), px.end(), lp->momMatrix[3 * n]) == px.end()) px.push_back(lp->momMatrix[3 * n]);
-    const size_t tileBytes = lp->loopBytes() * ((size_t)2 * lp->localL[3] * (lp->localL[0] + 1) + px.size() * (size_t)lp->localL[0]);
+    const size_t tileBytes = eo_dft_x_lds_bytes(lp->loopPrecision, lp->localL, (int)px.size(), nullptr);
     if (tileBytes <= 64 * 1024 && lp->localL[2] <= 65535 && lp->nData <= 65535) {
       if ((st = mugiq_hip_convert_and_project(lp->dataMom_d, lp->dataPos_d, lp->nData, lp->nLoop, lp->momMatrix.data(), lp->Nmom, lp->FTSign,
                                               lp->localL, lp->totalL, coord, lp->loopPrecision, nullptr, 0, lp->stream)))

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -199,43 +200,197 @@ constexpr int kEoYG = 2;  // y rows per workgroup (their checkerboard entries ar
 template <typename F> struct EoDftArgs {
   const Cplx<F> *in;   // dataPos [nData][2*volumeCB]
   Cplx<F> *out;        // T1 [Lz*Ly][nPx][M]
-  const Cplx<F> *ph;   // [nPx][Lx]
+  const Cplx<F> *ph;   // [Lx][nPxPad]: the phases of one x side by side (nPxPad = nPx rounded up to kEoCh, zero-filled)
   int X[4];
-  int volumeCB, nPx, M;
+  int volumeCB, nPx, nPxPad, M;
+  int tilesPerWg;      // pipelined kernel: consecutive y pairs per workgroup
+  int redOffset;       // complex elements from the tile to the partial-sum area (0: the tile itself, single pass)
 };
 
+// Measured on MI355X (48.48.24.24 fp64, 25 slots, 7 distinct p_x): the first version of this kernel let lane <-> (y, p_x, t)
+// read a data element AND a phase from LDS for every complex multiply-add -- 32 LDS bytes per 4 FMAs, four times what the
+// LDS pipe of a CU delivers at the fp64 FMA rate: 3.45 ms to read 8.49 GB (2.5 TB/s, 31 % of HBM).  Now lane <-> row (y, t),
+// wave <-> a class of x values (x = wave, wave + 4, ...): every staged element is read from LDS exactly once and feeds the
+// multiply-adds of ALL p_x; the phases of a wave's x are wave-uniform, so they come through the scalar cache (s_load) and
+// enter the FMAs as SGPR operands.  The four partial sums of a row are combined through LDS in a fixed order.
+constexpr int kEoCh = 8;  // p_x values per pass (accumulators per lane)
+
+// the sums of one staged tile (rows y0, y0 + 1 of plane z, all t) and their store; ends with the LDS still being read
+template <typename F> __device__ inline void eo_dft_x_sums(const EoDftArgs<F> &a, Cplx<F> *tile, int y0, int z, int idataTo) {
+  typedef F vec2 __attribute__((ext_vector_type(2)));
+  const int Lx = a.X[0], Ly = a.X[1], Lt = a.X[3], ld = Lx + 1;
+  const int rows = kEoYG * Lt, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const Cplx<F> *phc = a.ph;
+  for (int p0 = 0; p0 < a.nPx; p0 += kEoCh) {
+    const int cnt = a.nPx - p0 < kEoCh ? a.nPx - p0 : kEoCh;
+    for (int r0 = 0; r0 < rows; r0 += 64) {
+      const int row = r0 + lane < rows ? r0 + lane : rows - 1;
+      const Cplx<F> *rp = tile + row * ld;
+      Cplx<F> acc[kEoCh];
+#pragma unroll
+      for (int j = 0; j < kEoCh; j++) acc[j] = Cplx<F>{F(0), F(0)};
+      // wave-uniform address: the kEoCh phases of an x in one run of scalar loads (zero beyond the list); the operands of
+      // the next x are requested before the multiply-adds of this one (clamped index: no conditional load)
+      const MUGIQ_CONSTANT vec2 *fbase = as_constant(reinterpret_cast<const vec2 *>(phc)) + p0;
+      Cplx<F> vn = rp[wave < Lx ? wave : Lx - 1];
+      vec2 fn[kEoCh];
+#pragma unroll
+      for (int j = 0; j < kEoCh; j++) fn[j] = fbase[(wave < Lx ? wave : Lx - 1) * a.nPxPad + j];
+      for (int x = wave; x < Lx; x += 4) {
+        const Cplx<F> v = vn;
+        vec2 fv[kEoCh];
+#pragma unroll
+        for (int j = 0; j < kEoCh; j++) fv[j] = fn[j];
+        const int xn = x + 4 < Lx ? x + 4 : x;
+        vn = rp[xn];
+#pragma unroll
+        for (int j = 0; j < kEoCh; j++) fn[j] = fbase[xn * a.nPxPad + j];
+#pragma unroll
+        for (int j = 0; j < kEoCh; j++) cmadd(acc[j], v, Cplx<F>{fv[j].x, fv[j].y});
+      }
+      __syncthreads();  // everyone is done reading the tile rows (single pass) / the previous pass's partial sums
+      Cplx<F> *red = tile + a.redOffset;  // [kEoCh][4 waves][64 lanes]: consecutive lanes, consecutive 16-byte slots
+#pragma unroll
+      for (int j = 0; j < kEoCh; j++) red[(j * 4 + wave) * 64 + lane] = acc[j];
+      __syncthreads();
+      for (int o = threadIdx.x; o < 64 * cnt; o += 256) {
+        const int ln = o % 64, j = o / 64, rr = r0 + ln;
+        if (rr < rows) {
+          Cplx<F> s = red[(j * 4 + 0) * 64 + ln];
+#pragma unroll
+          for (int w = 1; w < 4; w++) {  // fixed order: x classes 0, 1, 2, 3
+            const Cplx<F> q = red[(j * 4 + w) * 64 + ln];
+            s.re += q.re;
+            s.im += q.im;
+          }
+          const int yy = rr / Lt, t = rr - yy * Lt;
+          a.out[((int64_t)(z * Ly + y0 + yy) * a.nPx + p0 + j) * a.M + t + Lt * idataTo] = s;
+        }
+      }
+    }
+  }
+}
+
+#if defined(MUGIQ_EO_EXPERIMENT) && MUGIQ_EO_EXPERIMENT == 2 /* probe 2: no global loads */
+#define MUGIQ_EO_LOAD(dst_, ptr_) dst_ = vec2{F(pty_), F(t_)};
+#else
+#define MUGIQ_EO_LOAD(dst_, ptr_) dst_ = __builtin_nontemporal_load(as_global(reinterpret_cast<const vec2 *>(ptr_)));
+#endif
+constexpr int kEoLd = 12;  // loads per lane that cover a whole tile in the pipelined kernel (48 x 24: 12)
+
+// Pipelined form (a run fits a wave and kEoLd loads per lane cover a tile): a workgroup walks `tilesPerWg` consecutive y
+// pairs of its (z, idataFrom); the loads of the NEXT tile are issued into registers as soon as the current one has been
+// committed to LDS, so they travel while the sums of the current tile are taken (the first version exposed the full
+// memory latency once per tile: ~10 us of workgroup lifetime for 37 KB of data).
+template <typename F> __global__ __launch_bounds__(256) void eo_dft_x_pipelined_kernel(EoDftArgs<F> a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int Lx = a.X[0], Ly = a.X[1], Lz = a.X[2], Lt = a.X[3], ld = Lx + 1;
+  Cplx<F> *tile = reinterpret_cast<Cplx<F> *>(smem);
+  const int z = blockIdx.y, idataFrom = blockIdx.z;
+  const int ig = idataFrom & 15;
+  const int idataTo = (15 - ig) + (idataFrom - ig);  // gammaMap->index[ig] + N_GAMMA_*iL   :89
+  const F sign = (F)kGammaMapSign[ig];               // gammaMap->sign[ig]                    :93
+  const Cplx<F> *src = a.in + (int64_t)idataFrom * 2 * a.volumeCB;
+  const int hx = Lx >> 1, run = kEoYG * hx, nRuns = 2 * Lt;
+  typedef F vec2 __attribute__((ext_vector_type(2)));
+  const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rpw = 64 / run, sub = ln / run;  // runs a wave fetches side by side (run <= 64)
+  const int groups = (nRuns + rpw - 1) / rpw;
+  const int r = ln - sub * run;
+  const bool idle = sub >= rpw;
+  const int rr = idle ? 0 : r;
+  const int yy = rr / hx, xh = rr - yy * hx;
+  // per load slot q: run group wv + 4 q -> (t, parity); recomputed where needed (a dozen integer instructions) instead of
+  // kept in 36 registers: with the stage registers live across the sums, the kernel must stay within 128 VGPRs to keep
+  // four waves per SIMD
+  const int tStride = (Lz * Ly * Lx) >> 1;                      // elements; the host guarantees 2 * volumeCB < 2^31
+  const int base = ((z * Ly * Lx) >> 1) + rr;
+  const int dstBase = yy * Lt * ld + 2 * xh, parBase = yy + z;   // y0 is even: the parity of y is that of yy
+  int tpLane = idle ? 0 : sub;
+#define MUGIQ_EO_SLOT(q_)                                                                        \
+  const int grp_ = wv + 4 * (q_) < groups ? wv + 4 * (q_) : groups - 1; /* surplus slots repeat the last group */ \
+  int tp_ = grp_ * rpw + tpLane;                                                                 \
+  tp_ = tp_ < nRuns ? tp_ : nRuns - 1;                                                           \
+  const int pty_ = tp_ & 1, t_ = tp_ >> 1;
+  const int tiles = Ly / kEoYG;
+  const int tb = blockIdx.x * a.tilesPerWg, te = tb + a.tilesPerWg < tiles ? tb + a.tilesPerWg : tiles;
+  vec2 u[kEoLd];
+#define MUGIQ_EO_FETCH(ty_)                                                                                          \
+  {                                                                                                                  \
+    const Cplx<F> *sp_ = src + (int64_t)(ty_) * run + base; /* rows y0 = kEoYG * ty: run = kEoYG * Lx / 2 entries further */ \
+    asm volatile("" : "+v"(tpLane)); /* keep the slot arithmetic here: hoisted out of the tile loop it costs 36 VGPRs */   \
+    _Pragma("unroll") for (int q = 0; q < kEoLd; q++) {                                                              \
+      MUGIQ_EO_SLOT(q)                                                                                               \
+      MUGIQ_EO_LOAD(u[q], sp_ + (pty_ * a.volumeCB + t_ * tStride))                                                  \
+    }                                                                                                                \
+  }
+  if (tb < te) MUGIQ_EO_FETCH(tb)
+  for (int ty = tb; ty < te; ty++) {
+    __syncthreads();  // the previous tile's sums and stores are done with the LDS
+    asm volatile("" : "+v"(tpLane));
+#pragma unroll
+    for (int q = 0; q < kEoLd; q++) {
+      MUGIQ_EO_SLOT(q)
+      tile[dstBase + t_ * ld + ((pty_ - (parBase + t_)) & 1)] = Cplx<F>{sign * u[q].x, sign * u[q].y};
+    }
+    if (ty + 1 < te) MUGIQ_EO_FETCH(ty + 1)
+    __syncthreads();
+#if !defined(MUGIQ_EO_EXPERIMENT) || MUGIQ_EO_EXPERIMENT != 1 /* probe 1: staging only */
+    eo_dft_x_sums(a, tile, ty * kEoYG, z, idataTo);
+#endif
+  }
+#undef MUGIQ_EO_SLOT
+#undef MUGIQ_EO_FETCH
+}
+
+// General form (any Lx, Lt): one tile per workgroup, loads in batches of kEoLd per lane
 template <typename F> __global__ __launch_bounds__(256) void eo_dft_x_kernel(EoDftArgs<F> a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int Lx = a.X[0], Ly = a.X[1], Lz = a.X[2], Lt = a.X[3], ld = Lx + 1;  // padded rows: lanes walk t at a fixed x
-  Cplx<F> *tile = reinterpret_cast<Cplx<F> *>(smem);                         // [kEoYG][Lt][Lx + 1]
-  Cplx<F> *phs = tile + kEoYG * Lt * ld;                                     // [nPx][Lx]
+  const int Lx = a.X[0], Ly = a.X[1], Lz = a.X[2], Lt = a.X[3], ld = Lx + 1;  // padded rows: lanes walk the rows at a fixed x
+  Cplx<F> *tile = reinterpret_cast<Cplx<F> *>(smem);                         // [kEoYG * Lt rows][Lx + 1]; later the partial sums
   const int y0 = blockIdx.x * kEoYG, z = blockIdx.y, idataFrom = blockIdx.z;
   const int ig = idataFrom & 15;
   const int idataTo = (15 - ig) + (idataFrom - ig);  // gammaMap->index[ig] + N_GAMMA_*iL   :89
   const F sign = (F)kGammaMapSign[ig];               // gammaMap->sign[ig]                    :93
   const Cplx<F> *src = a.in + (int64_t)idataFrom * 2 * a.volumeCB;
-  for (int i = threadIdx.x; i < a.nPx * Lx; i += 256) phs[i] = a.ph[i];
-  // per (t, parity): the kEoYG * Lx/2 checkerboard entries of rows y0, y0+1 are contiguous
-  const int hx = Lx >> 1, run = kEoYG * hx;
+  // per (t, parity): the kEoYG * Lx/2 checkerboard entries of rows y0, y0+1 are contiguous ("run"); a wave fetches 64-entry
+  // pieces of runs
+  const int hx = Lx >> 1, run = kEoYG * hx, nRuns = 2 * Lt;
   typedef F vec2 __attribute__((ext_vector_type(2)));
-  for (int i = threadIdx.x; i < 2 * Lt * run; i += 256) {
-    const int r = i % run, tp = i / run, pty = tp & 1, t = tp >> 1;
-    const int yy = r / hx, xh = r - yy * hx, y = y0 + yy;
-    const int x = 2 * xh + ((pty - (y + z + t)) & 1);
-    const int64_t x_cb = ((((int64_t)t * Lz + z) * Ly + y0) * Lx >> 1) + r;
-    const vec2 u = __builtin_nontemporal_load(as_global(reinterpret_cast<const vec2 *>(src + (int64_t)pty * a.volumeCB + x_cb)));
-    tile[(yy * Lt + t) * ld + x] = Cplx<F>{sign * u.x, sign * u.y};
+  const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int chunks = (run + 63) / 64;
+  const int items = nRuns * chunks;
+  for (int it0 = wv; it0 < items; it0 += 4 * kEoLd) {
+    vec2 u[kEoLd];
+    int dst[kEoLd];
+#pragma unroll
+    for (int q = 0; q < kEoLd; q++) {
+      const int it = it0 + 4 * q < items ? it0 + 4 * q : items - 1;  // surplus slots repeat the last item (same value, same place)
+      const int tp = it / chunks, ch = it - tp * chunks;
+      int r = ln + 64 * ch;
+      r = r < run ? r : 0;
+      const int pty = tp & 1, t = tp >> 1;
+      const int yy = r / hx, xh = r - yy * hx, y = y0 + yy;
+      const int x = 2 * xh + ((pty - (y + z + t)) & 1);
+      const int64_t x_cb = ((((int64_t)t * Lz + z) * Ly + y0) * Lx >> 1) + r;
+      u[q] = __builtin_nontemporal_load(as_global(reinterpret_cast<const vec2 *>(src + (int64_t)pty * a.volumeCB + x_cb)));
+      dst[q] = (yy * Lt + t) * ld + x;
+    }
+#pragma unroll
+    for (int q = 0; q < kEoLd; q++) tile[dst[q]] = Cplx<F>{sign * u[q].x, sign * u[q].y};
   }
   __syncthreads();
-  const int nOutB = kEoYG * a.nPx * Lt;
-  for (int o = threadIdx.x; o < nOutB; o += 256) {
-    const int t = o % Lt, rest = o / Lt, ipx = rest % a.nPx, yy = rest / a.nPx;
-    const Cplx<F> *row = tile + (yy * Lt + t) * ld;
-    const Cplx<F> *f = phs + ipx * Lx;
-    Cplx<F> acc{F(0), F(0)};
-    for (int x = 0; x < Lx; x++) cmadd(acc, row[x], f[x]);
-    a.out[((int64_t)(z * Ly + y0 + yy) * a.nPx + ipx) * a.M + t + Lt * idataTo] = acc;
-  }
+  eo_dft_x_sums(a, tile, y0, z, idataTo);
+}
+
+// LDS bytes of eo_dft_x_kernel: the tile, and the partial sums -- in the tile's place when one pass covers all rows (<= 64) and
+// all distinct p_x (<= kEoCh), behind it otherwise (a later pass needs the rows again)
+size_t eo_dft_x_lds_bytes(int precision, const int localL[4], int nPx, int *redOffsetElems) {
+  const size_t tile = (size_t)kEoYG * localL[3] * (localL[0] + 1), red = (size_t)4 * 64 * kEoCh;
+  const bool single = kEoYG * localL[3] <= 64 && nPx <= kEoCh;
+  if (redOffsetElems) *redOffsetElems = single ? 0 : (int)tile;
+  return (single ? std::max(tile, red) : tile + red) * 2 * (size_t)precision;
 }
 
 // the plan: distinct p_x, distinct (p_x, p_y) pairs, and the tables of the three steps
@@ -354,6 +509,14 @@ static int launch_separable(void *C, const void *A, const void *dataPosEO, int n
     phOff[d] = ph.size();
     phase_rows<F>(ph, *qs[d], localL[d], (commCoord ? commCoord[d] : 0) * localL[d], totalL[d], FTSign);
   }
+  // step x of the fused kernel reads the x phases transposed: [Lx][nPxPad], zero-filled (see eo_dft_x_kernel)
+  const int nPxPad = ((int)P.px.size() + kEoCh - 1) / kEoCh * kEoCh;
+  const size_t phXT = ph.size();
+  if (dataPosEO != nullptr) {
+    ph.resize(phXT + (size_t)localL[0] * nPxPad, Cplx<F>{F(0), F(0)});
+    for (size_t r = 0; r < P.px.size(); r++)
+      for (int x = 0; x < localL[0]; x++) ph[phXT + (size_t)x * nPxPad + r] = ph[phOff[0] + r * localL[0] + x];
+  }
   std::vector<int> ints;
   size_t iOff[3][5];
   for (int st = 0; st < 3; st++) {
@@ -382,12 +545,13 @@ static int launch_separable(void *C, const void *A, const void *dataPosEO, int n
   const int outer[3] = {localL[2] * localL[1], localL[2], 1};
   int firstStep = 0;
   if (dataPosEO != nullptr) {  // step x straight from the even-odd buffer (A, the reordered copy, is not needed)
-    const size_t shmem = sizeof(Cplx<F>) * ((size_t)kEoYG * localL[3] * (localL[0] + 1) + P.px.size() * (size_t)localL[0]);
-    MUGIQ_REQUIRE(shmem <= 64 * 1024 && localL[2] <= 65535 && nData <= 65535, "performMomentumProjection: lattice too large for the fused reorder + x step");
     EoDftArgs<F> e;
+    const size_t shmem = eo_dft_x_lds_bytes((int)sizeof(F), localL, (int)P.px.size(), &e.redOffset);
+    MUGIQ_REQUIRE(shmem <= 64 * 1024 && localL[2] <= 65535 && nData <= 65535, "performMomentumProjection: lattice too large for the fused reorder + x step");
     e.in = static_cast<const Cplx<F> *>(dataPosEO);
     e.out = t1;
-    e.ph = ph_d + phOff[0];
+    e.ph = ph_d + phXT;
+    e.nPxPad = nPxPad;
     long long vol = 1;
     for (int d = 0; d < 4; d++) {
       e.X[d] = localL[d];
@@ -396,7 +560,20 @@ static int launch_separable(void *C, const void *A, const void *dataPosEO, int n
     e.volumeCB = (int)(vol / 2);
     e.nPx = (int)P.px.size();
     e.M = M;
-    hipLaunchKernelGGL((eo_dft_x_kernel<F>), dim3(localL[1] / kEoYG, localL[2], nData), dim3(256), shmem, stream, e);
+    const int run = kEoYG * localL[0] / 2, tiles = localL[1] / kEoYG;
+    const bool pipelined = run <= 64 && (2 * localL[3] + 64 / run - 1) / (64 / run) <= 4 * kEoLd;
+    if (pipelined) {
+      // about 32 workgroups per CU (8 rounds of 4): enough to balance, few enough to amortise the pipeline fill
+      const long long slabs = (long long)localL[2] * nData;
+      int perWg = (int)((slabs * tiles + 8191) / 8192);
+      perWg = perWg < 1 ? 1 : (perWg > tiles ? tiles : perWg);
+      if (const char *t = getenv("MUGIQ_HIP_EO_TILES_PER_WG")) perWg = std::max(1, std::min(tiles, atoi(t)));
+      e.tilesPerWg = perWg;
+      hipLaunchKernelGGL((eo_dft_x_pipelined_kernel<F>), dim3((tiles + perWg - 1) / perWg, localL[2], nData), dim3(256), shmem, stream, e);
+    } else {
+      e.tilesPerWg = 1;
+      hipLaunchKernelGGL((eo_dft_x_kernel<F>), dim3(tiles, localL[2], nData), dim3(256), shmem, stream, e);
+    }
     MUGIQ_CHECK_HIP(hipGetLastError());
     firstStep = 1;
   }

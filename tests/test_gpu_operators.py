@@ -292,6 +292,27 @@ def test_convert_and_project_in_one_call(hip, prec, X, nLoop, coord, tot):
     assert rel_err(out.cpu().numpy(), exp) < (1e-13 if prec == 8 else 5e-6)
 
 
+@pytest.mark.parametrize("prec", [8, 4])
+@pytest.mark.parametrize("X,pxs", [((4, 2, 2, 40), [0, 1]), ((12, 2, 2, 4), list(range(-5, 6))), ((8, 4, 2, 36), list(range(-4, 6))),
+                                   ((32, 2, 2, 32), [0, 3, -1])])
+def test_convert_and_project_multi_pass_shapes(hip, prec, X, pxs):
+    """The fused reorder + x step keeps one row (y, t) per lane and 8 distinct p_x per pass: more than 64 rows (Lt > 32)
+    and more than 8 distinct p_x go through several passes over the staged tile."""
+    rng = np.random.default_rng(47)
+    V = int(np.prod(X))
+    nLoop, nData = 2, 32
+    cdt = _np_c(prec)
+    pos = (rng.standard_normal(nData * V) + 1j * rng.standard_normal(nData * V)).astype(cdt)
+    mom = [(px, py, (px + py) % 2) for px in pxs for py in (0, 1)]
+    locV3 = X[0] * X[1] * X[2]
+    out = torch.zeros(X[3] * nData * len(mom), dtype=torch.complex128 if prec == 8 else torch.complex64, device="cuda")
+    hip.convertAndProject(out, torch.from_numpy(pos).cuda(), nData, nLoop, mom, 1, X, X)
+    mp_ = orc.convert_idx_order_map_gamma(pos.astype(np.complex128), nData, nLoop, 2, V // 2, X)
+    ph = orc.phase_matrix(mom, locV3, 1, X, X, dtype=np.float64 if prec == 8 else np.float32)
+    exp = orc.momentum_projection_local(mp_, ph.astype(np.complex128), X[3], nData, locV3, len(mom))
+    assert rel_err(out.cpu().numpy(), exp) < (1e-13 if prec == 8 else 5e-6)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MUGIQ_TEST_SEEDS", 16))))
 def test_random_projection_shapes(hip, seed):
     """Seeded random local lattices, process grids / rank coordinates, momentum lists (unsorted, with repeats) and loop
