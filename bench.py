@@ -261,8 +261,12 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
         out["roofline"]["reflected_slots"] = roof("hbm", "reflect_kernel (%d slots)" % nref, ms_r, nref * V * 2 * 32 * B)
     ms_m = phase_sum(ph, "momentum_projection")
     nData = 16 * best["nLoop"]
-    out["roofline"]["momentum_projection"] = roof("hbm", "eo_dft_x_kernel + partial_dft_kernel (y, z)", ms_m, V * nData * 2 * B,
-                                                  note="algorithmic bytes = the position-space buffer read once; N_mom = %d" % len(moms))
+    npx = len(set(m[0] for m in moms))
+    out["roofline"]["momentum_projection"] = roof("hbm", "eo_dft_x (reorder + x sum) + partial_dft_kernel (y, z)", ms_m,
+                                                  V * nData * 2 * B * (1 + npx / X[0]),
+                                                  note="algorithmic bytes = the position-space buffer read once + the x-summed array (%d distinct p_x of "
+                                                       "%d momenta, 1/%d of the input per p_x) written once; the y and z steps work on arrays Lx and Lx*Ly "
+                                                       "times smaller and are counted in the time only" % (npx, len(moms), X[0]))
     out["momentum_copy_ms"] = phase_sum(ph, "momentum_copy")
     out["momentum_reduce_host_ms"] = phase_sum(ph, "momentum_reduce")
     halo = [p for p in ph if p["kind"] == "halo_transfer"]

@@ -279,69 +279,177 @@ template <typename F> __device__ inline void eo_dft_x_sums(const EoDftArgs<F> &a
 #endif
 constexpr int kEoLd = 12;  // loads per lane that cover a whole tile in the pipelined kernel (48 x 24: 12)
 
-// Pipelined form (a run fits a wave and kEoLd loads per lane cover a tile): a workgroup walks `tilesPerWg` consecutive y
-// pairs of its (z, idataFrom); the loads of the NEXT tile are issued into registers as soon as the current one has been
-// committed to LDS, so they travel while the sums of the current tile are taken (the first version exposed the full
-// memory latency once per tile: ~10 us of workgroup lifetime for 37 KB of data).
+// Staging of the pipelined kernels (a run fits a wave and kEoLd loads per lane cover a tile): lane <-> entry of a run, several
+// runs side by side when a run is shorter than half a wave; load slot q of wave wv <-> run group wv + 4 q.
+template <typename F> struct EoStager {
+  typedef F vec2 __attribute__((ext_vector_type(2)));
+  int wv, rpw, groups, nRuns, tStride, base, dstBase, parBase, tpLane, ld, run, volumeCB;
+  vec2 u[kEoLd];
+
+  __device__ inline void init(const EoDftArgs<F> &a, int z) {
+    const int Lx = a.X[0], Ly = a.X[1], Lz = a.X[2], Lt = a.X[3];
+    ld = Lx + 1;
+    const int hx = Lx >> 1;
+    run = kEoYG * hx;
+    nRuns = 2 * Lt;
+    const int ln = threadIdx.x & 63;
+    wv = threadIdx.x >> 6;
+    rpw = 64 / run;  // runs a wave fetches side by side (run <= 64)
+    const int sub = ln / run;
+    groups = (nRuns + rpw - 1) / rpw;
+    const bool idle = sub >= rpw;
+    const int rr = idle ? 0 : ln - sub * run;
+    const int yy = rr / hx, xh = rr - yy * hx;
+    tStride = (Lz * Ly * Lx) >> 1;  // elements; the host guarantees 2 * volumeCB < 2^31
+    base = ((z * Ly * Lx) >> 1) + rr;
+    dstBase = yy * Lt * ld + 2 * xh;
+    parBase = yy + z;  // y0 is even: the parity of y is that of yy
+    tpLane = idle ? 0 : sub;
+    volumeCB = a.volumeCB;
+  }
+  // (t, parity) of load slot q: recomputed where needed (a dozen integer instructions) instead of kept in 36 registers -- with
+  // the stage registers live across the sums the kernel must stay within 128 VGPRs to keep four waves per SIMD; the empty
+  // asm keeps hipcc from hoisting the arithmetic out of the tile loop again
+  __device__ inline void slot(int q, int &pty, int &t) const {
+    const int grp = wv + 4 * q < groups ? wv + 4 * q : groups - 1;  // surplus slots repeat the last group (same value, same place)
+    int tp = grp * rpw + tpLane;
+    tp = tp < nRuns ? tp : nRuns - 1;
+    pty = tp & 1;
+    t = tp >> 1;
+  }
+  __device__ inline void fetch(const Cplx<F> *src, int ty) {
+    const Cplx<F> *sp = src + (int64_t)ty * run + base;  // rows y0 = kEoYG * ty: run = kEoYG * Lx / 2 entries further
+    asm volatile("" : "+v"(tpLane));
+#pragma unroll
+    for (int q = 0; q < kEoLd; q++) {
+      int pty_, t_;
+      slot(q, pty_, t_);
+      MUGIQ_EO_LOAD(u[q], sp + (pty_ * volumeCB + t_ * tStride))
+    }
+  }
+  __device__ inline void commit(Cplx<F> *tile, F sign) {
+    asm volatile("" : "+v"(tpLane));
+#pragma unroll
+    for (int q = 0; q < kEoLd; q++) {
+      int pty_, t_;
+      slot(q, pty_, t_);
+      tile[dstBase + t_ * ld + ((pty_ - (parBase + t_)) & 1)] = Cplx<F>{sign * u[q].x, sign * u[q].y};
+    }
+  }
+};
+
+// Pipelined form: a workgroup walks `tilesPerWg` consecutive y pairs of its (z, idataFrom); the loads of the NEXT tile are issued
+// into registers as soon as the current one has been committed to LDS, so they travel while the sums of the current tile
+// are taken.
 template <typename F> __global__ __launch_bounds__(256) void eo_dft_x_pipelined_kernel(EoDftArgs<F> a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int Lx = a.X[0], Ly = a.X[1], Lz = a.X[2], Lt = a.X[3], ld = Lx + 1;
   Cplx<F> *tile = reinterpret_cast<Cplx<F> *>(smem);
   const int z = blockIdx.y, idataFrom = blockIdx.z;
   const int ig = idataFrom & 15;
   const int idataTo = (15 - ig) + (idataFrom - ig);  // gammaMap->index[ig] + N_GAMMA_*iL   :89
   const F sign = (F)kGammaMapSign[ig];               // gammaMap->sign[ig]                    :93
   const Cplx<F> *src = a.in + (int64_t)idataFrom * 2 * a.volumeCB;
-  const int hx = Lx >> 1, run = kEoYG * hx, nRuns = 2 * Lt;
-  typedef F vec2 __attribute__((ext_vector_type(2)));
-  const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int rpw = 64 / run, sub = ln / run;  // runs a wave fetches side by side (run <= 64)
-  const int groups = (nRuns + rpw - 1) / rpw;
-  const int r = ln - sub * run;
-  const bool idle = sub >= rpw;
-  const int rr = idle ? 0 : r;
-  const int yy = rr / hx, xh = rr - yy * hx;
-  // per load slot q: run group wv + 4 q -> (t, parity); recomputed where needed (a dozen integer instructions) instead of
-  // kept in 36 registers: with the stage registers live across the sums, the kernel must stay within 128 VGPRs to keep
-  // four waves per SIMD
-  const int tStride = (Lz * Ly * Lx) >> 1;                      // elements; the host guarantees 2 * volumeCB < 2^31
-  const int base = ((z * Ly * Lx) >> 1) + rr;
-  const int dstBase = yy * Lt * ld + 2 * xh, parBase = yy + z;   // y0 is even: the parity of y is that of yy
-  int tpLane = idle ? 0 : sub;
-#define MUGIQ_EO_SLOT(q_)                                                                        \
-  const int grp_ = wv + 4 * (q_) < groups ? wv + 4 * (q_) : groups - 1; /* surplus slots repeat the last group */ \
-  int tp_ = grp_ * rpw + tpLane;                                                                 \
-  tp_ = tp_ < nRuns ? tp_ : nRuns - 1;                                                           \
-  const int pty_ = tp_ & 1, t_ = tp_ >> 1;
-  const int tiles = Ly / kEoYG;
+  EoStager<F> st;
+  st.init(a, z);
+  const int tiles = a.X[1] / kEoYG;
   const int tb = blockIdx.x * a.tilesPerWg, te = tb + a.tilesPerWg < tiles ? tb + a.tilesPerWg : tiles;
-  vec2 u[kEoLd];
-#define MUGIQ_EO_FETCH(ty_)                                                                                          \
-  {                                                                                                                  \
-    const Cplx<F> *sp_ = src + (int64_t)(ty_) * run + base; /* rows y0 = kEoYG * ty: run = kEoYG * Lx / 2 entries further */ \
-    asm volatile("" : "+v"(tpLane)); /* keep the slot arithmetic here: hoisted out of the tile loop it costs 36 VGPRs */   \
-    _Pragma("unroll") for (int q = 0; q < kEoLd; q++) {                                                              \
-      MUGIQ_EO_SLOT(q)                                                                                               \
-      MUGIQ_EO_LOAD(u[q], sp_ + (pty_ * a.volumeCB + t_ * tStride))                                                  \
-    }                                                                                                                \
-  }
-  if (tb < te) MUGIQ_EO_FETCH(tb)
+  if (tb < te) st.fetch(src, tb);
   for (int ty = tb; ty < te; ty++) {
     __syncthreads();  // the previous tile's sums and stores are done with the LDS
-    asm volatile("" : "+v"(tpLane));
-#pragma unroll
-    for (int q = 0; q < kEoLd; q++) {
-      MUGIQ_EO_SLOT(q)
-      tile[dstBase + t_ * ld + ((pty_ - (parBase + t_)) & 1)] = Cplx<F>{sign * u[q].x, sign * u[q].y};
-    }
-    if (ty + 1 < te) MUGIQ_EO_FETCH(ty + 1)
+    st.commit(tile, sign);
+    if (ty + 1 < te) st.fetch(src, ty + 1);
     __syncthreads();
 #if !defined(MUGIQ_EO_EXPERIMENT) || MUGIQ_EO_EXPERIMENT != 1 /* probe 1: staging only */
     eo_dft_x_sums(a, tile, ty * kEoYG, z, idataTo);
 #endif
   }
-#undef MUGIQ_EO_SLOT
-#undef MUGIQ_EO_FETCH
+}
+
+// The same with the sums on the matrix pipe (fp64 only; MUGIQ_HIP_EO_MFMA selects it).  Per tile the sums are a small real
+// GEMM, out'[row][n'] = sum_k' A'[row][k'] B'[k'][n'], with the complex structure unfolded: k' = 2 x + (re | im of the
+// staged element), n' = 2 j + (re | im of the sum for p_x number j), B'[2x][2j] = Re f, B'[2x+1][2j] = -Im f,
+// B'[2x][2j+1] = Im f, B'[2x+1][2j+1] = Re f.  v_mfma_f64_16x16x4_f64 takes A[i = lane & 15][k = lane >> 4] and
+// B[k = lane >> 4][j = lane & 15], one double per lane, and returns C[row = (lane >> 4) + 4 r][col = lane & 15] in register r
+// (checked with exact integers by tools/probes/mfma_f64_probe.hip).  Wave w owns the x range [w Lx/4, (w+1) Lx/4): its B
+// fragments (the phases) are loaded ONCE into Lx/8 registers and stay there for the whole kernel -- no phase traffic at
+// all in the tile loop; an A fragment is one ds_read_b64 of the tile, every element of which is read exactly once.  The four
+// partial products of a row are combined through LDS in a fixed order.  On gfx950 an fp64 MFMA has the rate of the vector
+// FMAs and shares their pipe (profiles/r02_mfma_f64_probe.json): what it saves here is operand delivery, not arithmetic.
+constexpr int kEoMfmaLdC = 18; // padded row of the partial-product area (doubles)
+template <int NKS, int MB> __global__ __launch_bounds__(256) void eo_dft_x_mfma_kernel(EoDftArgs<double> a) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __align__(16) unsigned char smem[];
+  Cplx<double> *tile = reinterpret_cast<Cplx<double> *>(smem);
+  const int Lx = a.X[0], Ly = a.X[1], Lt = a.X[3], ld = Lx + 1;
+  const int z = blockIdx.y, idataFrom = blockIdx.z;
+  const int ig = idataFrom & 15;
+  const int idataTo = (15 - ig) + (idataFrom - ig);
+  const double sign = (double)kGammaMapSign[ig];
+  const Cplx<double> *src = a.in + (int64_t)idataFrom * 2 * a.volumeCB;
+  EoStager<double> st;
+  st.init(a, z);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rows = kEoYG * Lt, xw = wave * (Lx >> 2);  // NKS = Lx / 8 k-steps per wave, MB = ceil(rows / 16) row blocks: compile
+                                                       // time, so the tile loop is straight-line code (with run-time bounds
+                                                       // every MFMA sat in its own basic block behind its own LDS wait)
+  const int kq = lane >> 4, col = lane & 15;
+  // B fragments of this wave
+  double bfrag[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ks++) {
+    const int x = xw + 2 * ks + (kq >> 1), j = col >> 1;
+    const Cplx<double> f = a.ph[x * a.nPxPad + (j < a.nPx ? j : 0)];
+    const double v = (col & 1) == 0 ? ((kq & 1) == 0 ? f.re : -f.im) : ((kq & 1) == 0 ? f.im : f.re);
+    bfrag[ks] = j < a.nPx ? v : 0.0;
+  }
+  // A fragment addresses (doubles in the tile): row block mb, k-step ks -> ((row * ld + xw + 2 ks + (kq >> 1)) * 2 + (kq & 1))
+  int aoff[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++) {
+    const int row = 16 * mb + col < rows ? 16 * mb + col : rows - 1;
+    aoff[mb] = (row * ld + xw + (kq >> 1)) * 2 + (kq & 1);
+  }
+  const int tiles = Ly / kEoYG;
+  const int tb = blockIdx.x * a.tilesPerWg, te = tb + a.tilesPerWg < tiles ? tb + a.tilesPerWg : tiles;
+  if (tb < te) st.fetch(src, tb);
+  for (int ty = tb; ty < te; ty++) {
+    __syncthreads();  // the previous tile's partial products have been consumed
+    st.commit(tile, sign);
+    if (ty + 1 < te) st.fetch(src, ty + 1);
+    __syncthreads();
+    const double *td = reinterpret_cast<const double *>(tile);
+    d4 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) acc[mb] = d4{0, 0, 0, 0};
+    double af[NKS][MB];  // all A fragments of the tile first (NKS * MB LDS reads in flight), then the products
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++)
+#pragma unroll
+      for (int mb = 0; mb < MB; mb++) af[ks][mb] = td[aoff[mb] + 4 * ks];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++)
+#pragma unroll
+      for (int mb = 0; mb < MB; mb++) acc[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks][mb], bfrag[ks], acc[mb], 0, 0, 0);
+    __syncthreads();  // every wave is done reading the tile
+    double *red = reinterpret_cast<double *>(tile + a.redOffset);  // [4 waves][64 rows][kEoMfmaLdC]
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) red[((wave * 64) + 16 * mb + kq + 4 * r) * kEoMfmaLdC + col] = acc[mb][r];
+    __syncthreads();
+    const int y0 = ty * kEoYG;
+    for (int o = threadIdx.x; o < rows * a.nPx; o += 256) {
+      const int t = o % Lt, rest = o / Lt, j = rest % a.nPx, yy = rest / a.nPx, row = yy * Lt + t;
+      Cplx<double> s{0.0, 0.0};
+#pragma unroll
+      for (int w = 0; w < 4; w++) {  // fixed order: x ranges 0, 1, 2, 3
+        const double *q = red + ((w * 64) + row) * kEoMfmaLdC + 2 * j;
+        s.re += q[0];
+        s.im += q[1];
+      }
+      a.out[((int64_t)(z * Ly + y0 + yy) * a.nPx + j) * a.M + t + Lt * idataTo] = s;
+    }
+  }
 }
 
 // General form (any Lx, Lt): one tile per workgroup, loads in batches of kEoLd per lane
@@ -387,7 +495,8 @@ template <typename F> __global__ __launch_bounds__(256) void eo_dft_x_kernel(EoD
 // LDS bytes of eo_dft_x_kernel: the tile, and the partial sums -- in the tile's place when one pass covers all rows (<= 64) and
 // all distinct p_x (<= kEoCh), behind it otherwise (a later pass needs the rows again)
 size_t eo_dft_x_lds_bytes(int precision, const int localL[4], int nPx, int *redOffsetElems) {
-  const size_t tile = (size_t)kEoYG * localL[3] * (localL[0] + 1), red = (size_t)4 * 64 * kEoCh;
+  // (the matrix-pipe variant keeps [4][64][kEoMfmaLdC] doubles = 2304 complex there; it runs single pass only)
+  const size_t tile = (size_t)kEoYG * localL[3] * (localL[0] + 1), red = std::max<size_t>((size_t)4 * 64 * kEoCh, (size_t)4 * 64 * kEoMfmaLdC / 2);
   const bool single = kEoYG * localL[3] <= 64 && nPx <= kEoCh;
   if (redOffsetElems) *redOffsetElems = single ? 0 : (int)tile;
   return (single ? std::max(tile, red) : tile + red) * 2 * (size_t)precision;
@@ -562,6 +671,14 @@ static int launch_separable(void *C, const void *A, const void *dataPosEO, int n
     e.M = M;
     const int run = kEoYG * localL[0] / 2, tiles = localL[1] / kEoYG;
     const bool pipelined = run <= 64 && (2 * localL[3] + 64 / run - 1) / (64 / run) <= 4 * kEoLd;
+    // the sums on the matrix pipe where it applies (fp64; one pass: <= 64 rows, <= 8 distinct p_x; Lx = 24, 32, 48 or 64):
+    // 1.95 ms against 2.06 ms for the vector form at 48.48.24.24 x 25 slots (profiles/r02_eo_dft_x_kernel_stats_*.csv);
+    // MUGIQ_HIP_EO_MFMA = 0 keeps the vector form
+    bool mfma = true;
+    if (const char *m = getenv("MUGIQ_HIP_EO_MFMA")) mfma = atoi(m) != 0;
+    const int mfmaKs = localL[0] / 8, mfmaMb = (kEoYG * localL[3] + 15) / 16;
+    mfma = mfma && sizeof(F) == 8 && pipelined && kEoYG * localL[3] <= 64 && (int)P.px.size() <= 8 && localL[0] % 8 == 0 &&
+           (mfmaKs == 3 || mfmaKs == 4 || mfmaKs == 6 || mfmaKs == 8) && mfmaMb >= 2;
     if (pipelined) {
       // about 32 workgroups per CU (8 rounds of 4): enough to balance, few enough to amortise the pipeline fill
       const long long slabs = (long long)localL[2] * nData;
@@ -569,7 +686,19 @@ static int launch_separable(void *C, const void *A, const void *dataPosEO, int n
       perWg = perWg < 1 ? 1 : (perWg > tiles ? tiles : perWg);
       if (const char *t = getenv("MUGIQ_HIP_EO_TILES_PER_WG")) perWg = std::max(1, std::min(tiles, atoi(t)));
       e.tilesPerWg = perWg;
-      hipLaunchKernelGGL((eo_dft_x_pipelined_kernel<F>), dim3((tiles + perWg - 1) / perWg, localL[2], nData), dim3(256), shmem, stream, e);
+      if constexpr (sizeof(F) == 8) {
+        if (mfma) {
+          const dim3 grid((tiles + perWg - 1) / perWg, localL[2], nData);
+#define MUGIQ_EO_MFMA_CASE(K_, M_) \
+  if (mfmaKs == K_ && mfmaMb == M_) hipLaunchKernelGGL((eo_dft_x_mfma_kernel<K_, M_>), grid, dim3(256), shmem, stream, e);
+          MUGIQ_EO_MFMA_CASE(3, 2) MUGIQ_EO_MFMA_CASE(3, 3) MUGIQ_EO_MFMA_CASE(3, 4) MUGIQ_EO_MFMA_CASE(4, 2) MUGIQ_EO_MFMA_CASE(4, 3)
+          MUGIQ_EO_MFMA_CASE(4, 4) MUGIQ_EO_MFMA_CASE(6, 2) MUGIQ_EO_MFMA_CASE(6, 3) MUGIQ_EO_MFMA_CASE(6, 4) MUGIQ_EO_MFMA_CASE(8, 2)
+          MUGIQ_EO_MFMA_CASE(8, 3) MUGIQ_EO_MFMA_CASE(8, 4)
+#undef MUGIQ_EO_MFMA_CASE
+        }
+      }
+      if (!mfma)
+        hipLaunchKernelGGL((eo_dft_x_pipelined_kernel<F>), dim3((tiles + perWg - 1) / perWg, localL[2], nData), dim3(256), shmem, stream, e);
     } else {
       e.tilesPerWg = 1;
       hipLaunchKernelGGL((eo_dft_x_kernel<F>), dim3(tiles, localL[2], nData), dim3(256), shmem, stream, e);
