@@ -160,6 +160,17 @@ template <typename F, int G0, int G1> __device__ inline void trace_and_store_ran
   }
 }
 
+// the four gamma traces G0 .. G0 + 3 of a colour-traced spin matrix, returned instead of stored
+template <typename F, int G0> __device__ inline void traces_range(Cplx<F> out[4], const Cplx<F> acc[16]) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    Cplx<F> t{F(0), F(0)};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++) add_phase(t, kGammaPhase[G0 + i][s2], acc[s2 * 4 + kGammaColumn[G0 + i][s2]]);
+    out[i] = t;
+  }
+}
+
 // ---- QUDA even-odd index helpers (upstream QUDA index_helper.cuh) --------------
 __host__ __device__ inline void get_coords(int c[4], int x_cb, const int X[4], int parity) {
   const int za = x_cb / (X[0] >> 1);

@@ -432,6 +432,16 @@ template <typename F, typename A, int B> __global__ __launch_bounds__(256) void 
       if (r0 + i < NC && c0 + j < NC) out[(r0 + i) * NC + c0 + j] = acc[i][j];
 }
 
+// Aggregate of a workgroup.  The V rows of an aggregate are 32-byte pieces (two checkerboard entries of an x row of four
+// sites) of 128-byte lines that four x-adjacent aggregates share.  Workgroups are dealt round-robin over the 8 XCDs, so with
+// aggregate = blockIdx the four sharers sit on four XCDs and each pulls the line into its own L2.  Here XCD k walks the k-th
+// contiguous eighth of the lexicographic aggregate order, so the sharers run side by side on one XCD (measured: -8 % on both
+// congruence kernels at 32^4, n_vec 24).
+__device__ inline int xcd_contiguous_block(int blk, int nblk) {
+  if (nblk & 7) return blk;
+  return (blk & 7) * (nblk >> 3) + (blk >> 3);
+}
+
 template <typename F, typename A> struct FineCongruenceArgs {
   const Cplx<F> *V;       // [parity][(3s+c)*NV + j][x_cb]
   int64_t Vpo;
@@ -458,8 +468,7 @@ __global__ __launch_bounds__(4 * NH * SPR) void fine_congruence_kernel(FineCongr
   constexpr int LPS = 4 * NH, NT = LPS * SPR;  // lanes per site, threads per workgroup
   const int t = threadIdx.x, sidx = t / LPS, lane = t % LPS, hh = lane >> 2, q = lane & 3, chi = q >> 1, chip = q & 1;
 
-  // the aggregate: blockIdx.x runs lexicographically over the coarse lattice
-  int cc[4], r = blockIdx.x;
+  int cc[4], r = xcd_contiguous_block(blockIdx.x, gridDim.x);
 #pragma unroll
   for (int d = 0; d < 4; d++) {
     cc[d] = r % a.Xc[d];
@@ -561,6 +570,248 @@ __global__ __launch_bounds__(4 * NH * SPR) void fine_congruence_kernel(FineCongr
   }
 }
 
+// ---- the same congruence on the matrix pipe (fp64 accumulation; n_vec = 8, 16, 24, 32; aggregates of 16 k sites) ----------------
+// Per colour c and left spin be the first half of the congruence is a real GEMM shared by all sites of the aggregate:
+//   T(x; be, c; j'') = sum_j V(x; be, c, j) C[(chi(be), j), j''],   j'' = (chi', j') over the 2 n_vec columns of C(X),
+// i.e. T' = A' C' with the complex structure unfolded (k' <-> (j, re|im of V), n' = 2 j'' + re|im of T; C'[(j,re)][2j''] = Re C,
+// C'[(j,im)][2j''] = -Im C, C'[(j,re)][2j''+1] = Im C, C'[(j,im)][2j''+1] = Re C).  v_mfma_f64_16x16x4_f64 computes it
+// TRANSPOSED, D = C'^T A'^T: the A operand is a fragment of C'^T (lane: n' = 16 cb + (lane & 15), k = lane >> 4), the B operand
+// a fragment of A'^T (lane: k = lane >> 4, site = lane & 15), and lane l receives D[n' = 16 cb + (l >> 4) + 4 r][site = l & 15]
+// in register r -- the SITE stays on the lane, so the second half of the congruence,
+//   blk[be][al] += sum_{j'} T(be; chi(al), j') conj V(x; al, c, j'),
+// is plain per-lane arithmetic on the MFMA result (no transposition of T).  The order of the summation index inside a k-step
+// is free as long as both operands agree: k-steps 2 m and 2 m + 1 take Re and Im of V(.., j = 4 m + (lane >> 4)), so ONE
+// ds_read_b128 of the staged V tile feeds two MFMAs of a lane (with (j, re|im) in natural order every MFMA needed its own
+// ds_read_b64, and the LDS pipe, not the matrix pipe, set the pace).  Wave w <-> (chi, column block cb of 8 complex columns):
+// its n_vec / 2 fragments of C'^T stay in registers for the whole aggregate -- C(X) never enters LDS.  Per round 16 sites x 12
+// (spin, colour) rows of V are staged.  fp64 MFMA shares the fp64 vector pipe (profiles/r02_mfma_f64_probe.json): the gain is
+// operand delivery -- one LDS read feeds 2048 multiply-adds instead of 48.
+template <typename F> struct CongruenceMfmaArgs {
+  const Cplx<F> *V;       // [parity][(3s+c)*NV + j][x_cb]
+  int64_t Vpo;
+  int Vstride;
+  int X[4], Xc[4], bs[4];
+  int volumeCB, volumeCBc, aggVol;
+  const Cplx<double> *C;  // [2*volumeCBc][NC][NC]
+  Cplx<double> *loop;     // [16][V]
+};
+
+constexpr int kCmS = 16;  // sites per round = columns of one MFMA
+
+// GLDS (fp64 storage, two tiles fit the LDS): the next round's tile goes global -> LDS directly (global_load_lds_dwordx4, no
+// registers, no ds_write pass) into the other buffer while this round is consumed; otherwise (fp32 storage: the tile is
+// widened to double on the way; n_vec = 32: one buffer only) the next round waits in registers.
+template <typename F, int NV, bool GLDS> __global__ __launch_bounds__(64 * (NV / 2)) void fine_congruence_mfma_kernel(CongruenceMfmaArgs<F> a) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  typedef double vec2d __attribute__((ext_vector_type(2)));
+  typedef F vec2 __attribute__((ext_vector_type(2)));
+  constexpr int NC = 2 * NV, KS = NV / 2, NCB = NV / 4, NW = 2 * NCB, NT = 64 * NW;  // k-steps, column blocks, waves, threads
+  constexpr int ROWS = 12 * NV;                                                        // (spin, colour, j) rows of the V tile
+  constexpr int LDV = kCmS;                                                            // row of the V tile (complex)
+  constexpr int NLD = (ROWS * kCmS) / NT;                                              // staging loads per lane and round (= 6)
+  extern __shared__ __align__(16) unsigned char smem[];
+  Cplx<double> *Vs0 = reinterpret_cast<Cplx<double> *>(smem);  // [(s*3 + c)*NV + j][LDV], one or two buffers
+  double *red = reinterpret_cast<double *>(Vs0 + (GLDS ? 2 : 1) * ROWS * LDV);  // [NW][kCmS][8]: partial blk of every wave
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int chi = wave / NCB, cb = wave - chi * NCB;          // row block of C / left spins 2 chi, 2 chi + 1; column block
+  const int chip = cb / (NCB / 2), jb = (cb - chip * (NCB / 2)) * 8;  // right chirality of these columns; first j' of the block
+  const int kq = lane >> 4, site = lane & 15;
+
+  int cc[4], rr = xcd_contiguous_block(blockIdx.x, gridDim.x);
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    cc[d] = rr % a.Xc[d];
+    rr /= a.Xc[d];
+  }
+  const int cpar = (cc[0] + cc[1] + cc[2] + cc[3]) & 1;
+  const Cplx<double> *Cg = a.C + ((int64_t)cpar * a.volumeCBc + (lex_index(cc, a.Xc) >> 1)) * (int64_t)(NC * NC);
+  // resident fragments of C'^T: lane (n' = 16 cb + site, k = kq), k-steps 2 m | 2 m + 1 <-> (j = 4 m + kq, re | im):
+  // C[(chi NV + j), j''] with j'' = 8 cb + (site >> 1), output component site & 1
+  double cfrag[KS];
+#pragma unroll
+  for (int m = 0; m < KS / 2; m++) {
+    const Cplx<double> cv = Cg[(chi * NV + 4 * m + kq) * NC + 8 * cb + (site >> 1)];
+    cfrag[2 * m] = (site & 1) == 0 ? cv.re : cv.im;       // V_re contributes  Re C to T_re,  Im C to T_im
+    cfrag[2 * m + 1] = (site & 1) == 0 ? -cv.im : cv.re;  // V_im contributes -Im C to T_re,  Re C to T_im
+  }
+  // fine site (parity, x_cb) of aggregate member k (lexicographic inside the block)
+  auto member = [&](int k, int &pty, int &x_cb) {
+    int x[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      x[d] = cc[d] * a.bs[d] + k % a.bs[d];
+      k /= a.bs[d];
+    }
+    pty = (x[0] + x[1] + x[2] + x[3]) & 1;
+    x_cb = lex_index(x, a.X) >> 1;
+  };
+  // staging: element e = row * 16 + site of the round's tile, e = t + NT * q (six per lane for every n_vec); consecutive lanes
+  // take the 16 sites of a row, a wave instruction four consecutive rows = 1 KiB of the LDS image
+  vec2 u[GLDS ? 1 : NLD];
+  const int stSite = t & 15;
+  auto fetch = [&](int rd, Cplx<double> *buf) {
+    int pty, x_cb;
+    member(rd * kCmS + stSite, pty, x_cb);
+    const Cplx<F> *base = a.V + (int64_t)pty * a.Vpo + x_cb;
+#pragma unroll
+    for (int q = 0; q < NLD; q++) {
+      const int row = (t + NT * q) >> 4;
+      if constexpr (GLDS) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (a device-only builtin: the host pass of hipcc must not see it)
+        typedef __attribute__((address_space(3))) void lds_void;
+        __builtin_amdgcn_global_load_lds(as_global(reinterpret_cast<const vec2 *>(base + (int64_t)row * a.Vstride)),
+                                         (lds_void *)(buf + (wave * 64 + NT * q)), 16, 0, 0);
+#endif
+      } else {
+        u[q] = *as_global(reinterpret_cast<const vec2 *>(base + (int64_t)row * a.Vstride));
+      }
+    }
+  };
+  auto commit = [&](Cplx<double> *buf) {
+    if constexpr (!GLDS) {
+#pragma unroll
+      for (int q = 0; q < NLD; q++) buf[t + NT * q] = Cplx<double>{(double)u[q].x, (double)u[q].y};
+    }
+  };
+  // operand addresses (complex elements of the tile): B fragments of (be, c), k-step pair m: V(site; be, c, j = 4 m + kq);
+  // W(al, c, j' = jb + (kq >> 1) + 2 r)
+  const int bBase = kq * LDV + site, wBase = (jb + (kq >> 1)) * LDV + site;
+  const int rT = kq & 1;  // this lane holds Re (0) or Im (1) of T;  blk = T conj(W): Re += T_re W_re + T_im W_im, Im += T_im W_re - T_re W_im
+
+  const int rounds = a.aggVol / kCmS;
+  fetch(0, Vs0);
+  for (int rd = 0; rd < rounds; rd++) {
+    Cplx<double> *Vs = Vs0 + (GLDS ? (rd & 1) * ROWS * LDV : 0);
+    if constexpr (GLDS) {
+      // my share of this round's tile has landed; after the barrier everybody's has, and nobody reads the other buffer or
+      // the partial sums of the previous round any more
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (rd + 1 < rounds) fetch(rd + 1, Vs0 + ((rd + 1) & 1) * ROWS * LDV);
+    } else {
+      __syncthreads();  // the previous round's consumers are done with Vs / red
+      commit(Vs);
+      if (rd + 1 < rounds) fetch(rd + 1, Vs);
+      __syncthreads();
+    }
+    // the lanes that will store this round's traces (wave 0: site t >> 2, gamma channels 4 (t & 3) .. + 3) fetch the loop values
+    // they accumulate into NOW, not in the store phase every other wave then waits for at the next barrier
+    Cplx<double> oldv[4];
+    int outIdx = 0;
+    if (t < 4 * kCmS) {
+      int pty, x_cb;
+      member(rd * kCmS + (t >> 2), pty, x_cb);
+      outIdx = x_cb + pty * a.volumeCB;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const vec2d o = *as_global(reinterpret_cast<const vec2d *>(a.loop + (int64_t)(2 * a.volumeCB) * (4 * (t & 3) + i) + outIdx));
+        oldv[i] = Cplx<double>{o.x, o.y};
+      }
+    }
+    double blk[2][2][2];  // [be - 2 chi][al - 2 chip][re | im]
+#pragma unroll
+    for (int i = 0; i < 8; i++) (&blk[0][0][0])[i] = 0.0;
+    // Six units (colour c, left spin be): the B fragments of unit u + 1 are requested BEFORE the MFMAs of unit u, so the LDS
+    // reads run under the matrix pipe (with load-then-multiply per unit the twelve waves of the workgroup -- in step after
+    // every barrier -- all read LDS, then all multiply: the two times added up).  The W values of stage two do not depend on
+    // be: read once per colour.
+    Cplx<double> bfA[KS / 2], bfB[KS / 2], w[2][4];
+#define MUGIQ_CM_LOAD_B(bf_, u_)                                                                          \
+  {                                                                                                       \
+    const int rowB_ = ((2 * chi + ((u_) & 1)) * 3 + ((u_) >> 1)) * NV;                                    \
+    _Pragma("unroll") for (int m = 0; m < KS / 2; m++) bf_[m] = Vs[(rowB_ + 4 * m) * LDV + bBase];        \
+  }
+#define MUGIQ_CM_UNIT(bf_, bfNext_, u_)                                                                   \
+  {                                                                                                       \
+    if ((u_) + 1 < 6) MUGIQ_CM_LOAD_B(bfNext_, (u_) + 1)                                                  \
+    if (((u_) & 1) == 0) {                                                                                \
+      _Pragma("unroll") for (int ai = 0; ai < 2; ai++)                                                    \
+        _Pragma("unroll") for (int r = 0; r < 4; r++)                                                     \
+          w[ai][r] = Vs[(((2 * chip + ai) * 3 + ((u_) >> 1)) * NV + 2 * r) * LDV + wBase];                \
+    }                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0); /* the reads above stay above the MFMAs (hipcc sinks them next to their use) */ \
+    d4 acc = {0, 0, 0, 0};                                                                                \
+    _Pragma("unroll") for (int m = 0; m < KS / 2; m++) {                                                  \
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cfrag[2 * m], bf_[m].re, acc, 0, 0, 0);                  \
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cfrag[2 * m + 1], bf_[m].im, acc, 0, 0, 0);              \
+    }                                                                                                     \
+    /* acc[r] = Re|Im (kq & 1) of T(site; be, c; chi', j' = jb + (kq >> 1) + 2 r) */                      \
+    _Pragma("unroll") for (int ai = 0; ai < 2; ai++)                                                      \
+      _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                     \
+        const double wa = rT == 0 ? w[ai][r].re : w[ai][r].im;   /* multiplies into Re blk */             \
+        const double wb = rT == 0 ? -w[ai][r].im : w[ai][r].re;  /* multiplies into Im blk */             \
+        blk[(u_) & 1][ai][0] = fma(acc[r], wa, blk[(u_) & 1][ai][0]);                                     \
+        blk[(u_) & 1][ai][1] = fma(acc[r], wb, blk[(u_) & 1][ai][1]);                                     \
+      }                                                                                                   \
+  }
+    MUGIQ_CM_LOAD_B(bfA, 0)
+    MUGIQ_CM_UNIT(bfA, bfB, 0)
+    MUGIQ_CM_UNIT(bfB, bfA, 1)
+    MUGIQ_CM_UNIT(bfA, bfB, 2)
+    MUGIQ_CM_UNIT(bfB, bfA, 3)
+    MUGIQ_CM_UNIT(bfA, bfB, 4)
+    MUGIQ_CM_UNIT(bfB, bfA, 5)
+#undef MUGIQ_CM_UNIT
+#undef MUGIQ_CM_LOAD_B
+    // sum the four kq groups of a site (lanes l, l ^ 16, l ^ 32, l ^ 48), then hand the wave's partial block to LDS
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      double v = (&blk[0][0][0])[i];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      (&blk[0][0][0])[i] = v;
+    }
+    if (kq == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) red[(wave * kCmS + site) * 8 + i] = (&blk[0][0][0])[i];
+    }
+    // LDS-only barrier: __syncthreads() would also wait for the global -> LDS transfers of the next round (vmcnt(0))
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // full[al * 4 + be] = sum over the NCB / 2 waves of (chi(be), chi'(al)), fixed order; 4 of the 16 gamma traces per lane
+    if (t < 4 * kCmS) {
+      const int s = t >> 2, q = t & 3;
+      Cplx<double> full[16];
+#pragma unroll
+      for (int al = 0; al < 4; al++)
+#pragma unroll
+        for (int be = 0; be < 4; be++) {
+          const int w0 = (be >> 1) * NCB + (al >> 1) * (NCB / 2);
+          double re = 0.0, im = 0.0;
+#pragma unroll
+          for (int wv = 0; wv < NCB / 2; wv++) {
+            const double *p = red + ((w0 + wv) * kCmS + s) * 8 + ((be & 1) * 2 + (al & 1)) * 2;
+            re += p[0];
+            im += p[1];
+          }
+          full[al * 4 + be] = Cplx<double>{re, im};
+        }
+      Cplx<double> tr[4];
+      if (q == 0) traces_range<double, 0>(tr, full);
+      else if (q == 1) traces_range<double, 4>(tr, full);
+      else if (q == 2) traces_range<double, 8>(tr, full);
+      else traces_range<double, 12>(tr, full);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        a.loop[(int64_t)(2 * a.volumeCB) * (4 * q + i) + outIdx] = Cplx<double>{oldv[i].re + tr[i].re, oldv[i].im + tr[i].im};
+    }
+  }
+}
+
+template <typename F, int NV> static int launch_congruence_mfma(const CongruenceMfmaArgs<F> &a, hipStream_t stream) {
+  constexpr int NW = NV / 2;
+  constexpr size_t tileB = sizeof(Cplx<double>) * (size_t)12 * NV * kCmS, redB = sizeof(double) * (size_t)NW * kCmS * 8;
+  constexpr bool GLDS = sizeof(F) == 8 && 2 * tileB + redB <= 160 * 1024;
+  const size_t shmem = (GLDS ? 2 : 1) * tileB + redB;
+  auto kern = fine_congruence_mfma_kernel<F, NV, GLDS>;
+  if (shmem > 64 * 1024)
+    MUGIQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(kern, dim3(2 * a.volumeCBc), dim3(64 * NW), shmem, stream, a);
+  MUGIQ_CHECK_HIP(hipGetLastError());
+  return MUGIQ_HIP_SUCCESS;
+}
+
 // LDS bytes of the congruence kernel; 0 if this (n_vec, precision) does not fit
 template <typename F, typename A> static size_t congruence_lds(int NV, int SPR) {
   const size_t NC = 2 * (size_t)NV;
@@ -628,6 +879,36 @@ static int coarse_plan(const MugiqHipTransfer *T, const MugiqHipCoarseField *coa
   }
   MUGIQ_CHECK_HIP(hipGetLastError());
 
+  // fp64 accumulation, n_vec = 8, 16, 24, 32, aggregates of a multiple of 16 sites: the congruence on the matrix pipe
+  // (MUGIQ_HIP_MG_MFMA=0 keeps the vector kernel)
+  if constexpr (sizeof(A) == 8) {
+    bool mfma = (NV == 8 || NV == 16 || NV == 24 || NV == 32) && aggVol % kCmS == 0;
+    if (const char *e = getenv("MUGIQ_HIP_MG_MFMA")) mfma = mfma && atoi(e) != 0;
+    if (mfma) {
+      CongruenceMfmaArgs<F> m;
+      m.V = static_cast<const Cplx<F> *>(T->V);
+      m.Vpo = T->parity_offset;
+      m.Vstride = T->stride;
+      long long volf = 1;
+      for (int d = 0; d < 4; d++) {
+        m.X[d] = T->X[d];
+        m.bs[d] = T->geoBlockSize[d];
+        m.Xc[d] = T->X[d] / T->geoBlockSize[d];
+        volf *= T->X[d];
+      }
+      m.volumeCB = (int)(volf / 2);
+      m.volumeCBc = (int)(volc / 2);
+      m.aggVol = (int)aggVol;
+      m.C = reinterpret_cast<const Cplx<double> *>(o.C);
+      m.loop = static_cast<Cplx<double> *>(loop_d);
+      switch (NV) {
+      case 8: return launch_congruence_mfma<F, 8>(m, stream);
+      case 16: return launch_congruence_mfma<F, 16>(m, stream);
+      case 24: return launch_congruence_mfma<F, 24>(m, stream);
+      default: return launch_congruence_mfma<F, 32>(m, stream);
+      }
+    }
+  }
   FineCongruenceArgs<F, A> a;
   a.V = static_cast<const Cplx<F> *>(T->V);
   a.Vpo = T->parity_offset;
