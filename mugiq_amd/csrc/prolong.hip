@@ -583,7 +583,9 @@ __global__ __launch_bounds__(4 * NH * SPR) void fine_congruence_kernel(FineCongr
 // is free as long as both operands agree: k-steps 2 m and 2 m + 1 take Re and Im of V(.., j = 4 m + (lane >> 4)), so ONE
 // ds_read_b128 of the staged V tile feeds two MFMAs of a lane (with (j, re|im) in natural order every MFMA needed its own
 // ds_read_b64, and the LDS pipe, not the matrix pipe, set the pace).  Wave w <-> (chi, column block cb of 8 complex columns):
-// its n_vec / 2 fragments of C'^T stay in registers for the whole aggregate -- C(X) never enters LDS.  Per round 16 sites x 12
+// its n_vec / 2 fragments of C'^T stay in registers for the whole aggregate -- C(X) never enters LDS.  (Tried: four waves, one
+// per SIMD, each owning a whole 2 x 2 block with n_vec / 8 independent accumulator chains, one barrier per round, a third of the
+// B-fragment reads -- 5.1 ms against 3.6 ms: with one wave per SIMD nothing hides the LDS latency of stage two and the staging.)  Per round 16 sites x 12
 // (spin, colour) rows of V are staged.  fp64 MFMA shares the fp64 vector pipe (profiles/r02_mfma_f64_probe.json): the gain is
 // operand delivery -- one LDS read feeds 2048 multiply-adds instead of 48.
 template <typename F> struct CongruenceMfmaArgs {
@@ -603,7 +605,6 @@ constexpr int kCmS = 16;  // sites per round = columns of one MFMA
 // widened to double on the way; n_vec = 32: one buffer only) the next round waits in registers.
 template <typename F, int NV, bool GLDS> __global__ __launch_bounds__(64 * (NV / 2)) void fine_congruence_mfma_kernel(CongruenceMfmaArgs<F> a) {
   typedef double d4 __attribute__((ext_vector_type(4)));
-  typedef double vec2d __attribute__((ext_vector_type(2)));
   typedef F vec2 __attribute__((ext_vector_type(2)));
   constexpr int NC = 2 * NV, KS = NV / 2, NCB = NV / 4, NW = 2 * NCB, NT = 64 * NW;  // k-steps, column blocks, waves, threads
   constexpr int ROWS = 12 * NV;                                                        // (spin, colour, j) rows of the V tile
@@ -694,20 +695,6 @@ template <typename F, int NV, bool GLDS> __global__ __launch_bounds__(64 * (NV /
       if (rd + 1 < rounds) fetch(rd + 1, Vs);
       __syncthreads();
     }
-    // the lanes that will store this round's traces (wave 0: site t >> 2, gamma channels 4 (t & 3) .. + 3) fetch the loop values
-    // they accumulate into NOW, not in the store phase every other wave then waits for at the next barrier
-    Cplx<double> oldv[4];
-    int outIdx = 0;
-    if (t < 4 * kCmS) {
-      int pty, x_cb;
-      member(rd * kCmS + (t >> 2), pty, x_cb);
-      outIdx = x_cb + pty * a.volumeCB;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const vec2d o = *as_global(reinterpret_cast<const vec2d *>(a.loop + (int64_t)(2 * a.volumeCB) * (4 * (t & 3) + i) + outIdx));
-        oldv[i] = Cplx<double>{o.x, o.y};
-      }
-    }
     double blk[2][2][2];  // [be - 2 chi][al - 2 chip][re | im]
 #pragma unroll
     for (int i = 0; i < 8; i++) (&blk[0][0][0])[i] = 0.0;
@@ -792,9 +779,18 @@ template <typename F, int NV, bool GLDS> __global__ __launch_bounds__(64 * (NV /
       else if (q == 1) traces_range<double, 4>(tr, full);
       else if (q == 2) traces_range<double, 8>(tr, full);
       else traces_range<double, 12>(tr, full);
+      // loopData += trace, as fire-and-forget fp64 atomic adds: a read-modify-write would have to wait for its load, and a
+      // wait for ANY load result also waits for the global -> LDS transfers of the next round issued before it (one in-order
+      // counter) -- a full memory latency per round on wave 0, with the other eleven waves parked at the next barrier
+      // (measured: 0.5 ms of 4.1).  Every element receives exactly one addend per call, so the result does not depend on order.
+      int pty, x_cb;
+      member(rd * kCmS + s, pty, x_cb);
+      double *out = reinterpret_cast<double *>(a.loop + (int64_t)(2 * a.volumeCB) * (4 * q) + x_cb + pty * a.volumeCB);
 #pragma unroll
-      for (int i = 0; i < 4; i++)
-        a.loop[(int64_t)(2 * a.volumeCB) * (4 * q + i) + outIdx] = Cplx<double>{oldv[i].re + tr[i].re, oldv[i].im + tr[i].im};
+      for (int i = 0; i < 4; i++) {
+        unsafeAtomicAdd(out + (int64_t)(4 * a.volumeCB) * i, tr[i].re);
+        unsafeAtomicAdd(out + (int64_t)(4 * a.volumeCB) * i + 1, tr[i].im);
+      }
     }
   }
 }
