@@ -74,11 +74,7 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
   const int lane = threadIdx.x & 63;
   const int col = lane & 31, half = lane >> 5;
   const int wave = threadIdx.x >> 6;
-#if defined(MUGIQ_TILE_EXPERIMENT) && MUGIQ_TILE_EXPERIMENT == 1
-  const bool computes = false;  // diagnostic build: staging traffic only
-#else
   const bool computes = wave < kTileTJ * a.nslot;
-#endif
   const int NP = (DIR >= 1) ? kTileTJ + a.kmax : kTileTJ;
   const int J = a.X[DIR];
 
@@ -199,29 +195,17 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
   for (int i = 0; i < 8; i++) acc[i] = Cplx<A>{A(0), A(0)};
 
   typedef F vec2 __attribute__((ext_vector_type(2)));
-  // Three eigenvectors in flight ahead of the one being consumed.  Diagnostic builds on MI355X (-DMUGIQ_TILE_EXPERIMENT,
-  // 48.48.24.24 fp64, 100 eigenvectors, 10.0 ms per entry): staging only 5.9 ms, compute only 7.0 ms (6.9 ms without the
+  // Three eigenvectors in flight ahead of the one being consumed.  Diagnostic builds on MI355X (tools/probes/
+  // fused_tile_probes.patch; 48.48.24.24 fp64, 100 eigenvectors, 10.0 ms per entry): staging only 5.9 ms, compute only 7.0 ms (6.9 ms without the
   // barrier); SQ counters: the VALU pipe of a SIMD is ~64 % busy, 82 % of its instructions are the FMAs of the
   // mathematics -- the kernel is bound by vector issue, not by HBM or LDS.  Tried without gain: 6-deep prefetch for
   // fp32 storage (25 % slower), a pair-wise LDS layout so that fp32 reads are ds_read_b128 instead of ds_read2_b64 (no
   // change), column groups as the fastest workgroup index (4 % slower).
-  const Cplx<F> *body0 = static_cast<const Cplx<F> *>(a.L[0]);
-  (void)body0;
   constexpr int kDepth = sizeof(F) == 8 ? 2 : 3;  // eigenvectors in flight ahead of the one being consumed
   vec2 stageA[PH], stageB[PH], stageC[PH];
   // fetch this lane's share of eigenvector n_: plane `wave`, column `col`, positions pp = 2*i + half
-#if defined(MUGIQ_TILE_EXPERIMENT) && MUGIQ_TILE_EXPERIMENT == 4 /* diagnostic: no table look-ups (contiguous fields) */
-#define MUGIQ_TILE_BODY(n_) (body0 + (int64_t)(n_) * 2 * a.parity_offset)
-#define MUGIQ_TILE_SIGMA(n_) A(1)
-#else
 #define MUGIQ_TILE_BODY(n_) static_cast<const Cplx<F> *>(as_constant(a.L)[n_])
 #define MUGIQ_TILE_SIGMA(n_) as_constant(a.inv_sigma)[n_]
-#define MUGIQ_TILE_SCALAR_PREFETCH 1
-#endif
-#if defined(MUGIQ_TILE_EXPERIMENT) && (MUGIQ_TILE_EXPERIMENT == 2 || MUGIQ_TILE_EXPERIMENT == 3)
-#define MUGIQ_TILE_FETCH(n_, stage) { _Pragma("unroll") for (int i = 0; i < PH; i++) stage[i] = vec2{F(n_), F(1)}; } /* diagnostic: no global loads */
-#define MUGIQ_TILE_FETCH_AT(bodyExpr_, n_, stage) MUGIQ_TILE_FETCH(n_, stage)
-#else
 #define MUGIQ_TILE_FETCH(n_, stage) MUGIQ_TILE_FETCH_AT(MUGIQ_TILE_BODY(n_), n_, stage)
 #define MUGIQ_TILE_FETCH_AT(bodyExpr_, n_, stage)                                                                      \
   {                                                                                                                    \
@@ -232,21 +216,16 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
       stage[i] = *as_global(reinterpret_cast<const vec2 *>(ptr_));                                                     \
     }                                                                                                                  \
   }
-#endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() lowers to `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`,
 // i.e. it also drains every global load in flight -- which would serialise the register prefetch of the next
 // eigenvectors behind each barrier.  The stage registers are guarded by the compiler's own counted vmcnt waits.
-#if defined(MUGIQ_TILE_EXPERIMENT) && MUGIQ_TILE_EXPERIMENT == 3
-#define MUGIQ_LDS_BARRIER() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } /* diagnostic: no barrier (racy) */
-#else
 #define MUGIQ_LDS_BARRIER()                              \
   {                                                      \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
     __builtin_amdgcn_s_barrier();                        \
     asm volatile("" ::: "memory");                       \
   }
-#endif
 
 // One step: eigenvector n_ is in LDS buffer n_ % 2; `stage` holds eigenvector n_+1 (fetched three steps ago).
 // Commit n_+1 into the other buffer (everyone finished reading it before the barrier that ended the previous step),

@@ -272,11 +272,7 @@ template <typename F> __device__ inline void eo_dft_x_sums(const EoDftArgs<F> &a
   }
 }
 
-#if defined(MUGIQ_EO_EXPERIMENT) && MUGIQ_EO_EXPERIMENT == 2 /* probe 2: no global loads */
-#define MUGIQ_EO_LOAD(dst_, ptr_) dst_ = vec2{F(pty_), F(t_)};
-#else
 #define MUGIQ_EO_LOAD(dst_, ptr_) dst_ = __builtin_nontemporal_load(as_global(reinterpret_cast<const vec2 *>(ptr_)));
-#endif
 constexpr int kEoLd = 12;  // loads per lane that cover a whole tile in the pipelined kernel (48 x 24: 12)
 
 // Staging of the pipelined kernels (a run fits a wave and kEoLd loads per lane cover a tile): lane <-> entry of a run, several
@@ -359,9 +355,7 @@ template <typename F> __global__ __launch_bounds__(256) void eo_dft_x_pipelined_
     st.commit(tile, sign);
     if (ty + 1 < te) st.fetch(src, ty + 1);
     __syncthreads();
-#if !defined(MUGIQ_EO_EXPERIMENT) || MUGIQ_EO_EXPERIMENT != 1 /* probe 1: staging only */
     eo_dft_x_sums(a, tile, ty * kEoYG, z, idataTo);
-#endif
   }
 }
 
