@@ -250,6 +250,58 @@ static int entry_basic(MugiqHipLoop *lp, int id, void *slot0) {
   return MUGIQ_HIP_SUCCESS;
 }
 
+// The same sequence for a block of eigenvectors at a time (OPT plan, displacement longer than the local extent of a
+// partitioned dimension: the multi-layer halo cannot reach past the nearest neighbour, single steps can): per step ONE
+// message carries the faces of all eigenvectors of the block and ONE contraction launch takes the whole block, instead of
+// one exchange and one launch per eigenvector and step (thousands of small messages at configs[2] sizes).
+static int entry_stepwise_blocked(MugiqHipLoop *lp, int id, void *slot0) {
+  const int dir = lp->dispDir[id], sign = lp->dispSign[id], start = lp->dispStart[id], stop = lp->dispStop[id];
+  const bool part = lp->commDim[dir] != 0;
+  const size_t fieldB = (size_t)2 * lp->eVecs[0].parity_offset * lp->cplxBytes();
+  const size_t faceB = (size_t)24 * (lp->volumeCB / lp->localL[dir]) * lp->cplxBytes();
+  const size_t budget = (size_t)8 << 30;  // two auxiliary fields per eigenvector of the block
+  const int nb = (int)std::max<size_t>(1, std::min<size_t>((size_t)lp->nEv, budget / (2 * fieldB)));
+  int st;
+  std::vector<MugiqHipSpinorField> aux[2];
+  for (int h = 0; h < 2; h++) {
+    aux[h].resize(nb);
+    for (int i = 0; i < nb; i++)
+      if ((st = make_scratch_field(lp, &aux[h][i], lp->order, false, true))) return st;  // fully written by every displacement
+  }
+  void *gsend = nullptr, *grecv = nullptr;
+  if (part) {
+    if ((st = scratch_alloc(lp, &gsend, faceB * nb, false))) return st;
+    if ((st = scratch_alloc(lp, &grecv, faceB * nb, false))) return st;
+  }
+  const size_t slotBytes = (size_t)lp->nElemPosLocPerLoop * lp->loopBytes();
+  const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;  // sign +: my LOW face feeds the backward neighbour
+  std::vector<MugiqHipSpinorField> cur(nb);
+  for (int n0 = 0; n0 < lp->nEv; n0 += nb) {
+    const int nv = std::min(nb, lp->nEv - n0);
+    for (int i = 0; i < nv; i++) cur[i] = lp->eVecs[n0 + i];
+    for (int idisp = 1; idisp <= stop; idisp++) {
+      if (part) {
+        if ((st = mugiq_hip_pack_face_layers(gsend, cur.data(), nv, dir, high, 1, lp->stream))) return st;
+        st = lp->comm.sendrecv(lp->comm.ctx, gsend, grecv, faceB * nv, dir, high ? +1 : -1, lp->stream);
+        if (st) return set_error(MUGIQ_HIP_ERROR_HIP, "halo sendrecv callback failed with status %d", st);
+      }
+      for (int i = 0; i < nv; i++) {
+        if (part) cur[i].ghost[dir][sign == MUGIQ_HIP_DISP_SIGN_PLUS ? 1 : 0] = static_cast<char *>(grecv) + faceB * i;
+        MugiqHipSpinorField *dst = &aux[idisp & 1][i];
+        if ((st = mugiq_hip_perform_covariant_displacement_vector(dst, &cur[i], &lp->gauge, dir, sign, lp->commDim, lp->stream))) return st;
+        cur[i] = *dst;
+      }
+      if (idisp >= start) {
+        void *slot = static_cast<char *>(slot0) + slotBytes * (size_t)(idisp - start);
+        if ((st = mugiq_hip_perform_loop_contraction_batched_mixed(slot, lp->loopPrecision, &lp->eVecs[n0], cur.data(), &lp->sigma[n0], nv,
+                                                                   lp->stream)))
+          return st;
+      }
+    }
+  }
+  return MUGIQ_HIP_SUCCESS;
+}
+
 // path-ordered link products W_k as E_k = D^k E_0, E_0(x)(s,c) = delta_sc, s < 3 (scratch fields; k = 0 .. stop)
 static int build_path_links(MugiqHipLoop *lp, int id, std::vector<MugiqHipSpinorField> &E) {
   const int dir = lp->dispDir[id], sign = lp->dispSign[id], stop = lp->dispStop[id];
@@ -332,7 +384,7 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
   int st;
   // a displacement longer than the local extent of a partitioned dimension reaches past the nearest neighbour: the
   // multi-layer halo cannot serve it, the step-by-step sequence (one face per step) can
-  if (part && stop > lp->localL[dir]) return entry_basic(lp, id, slot0);
+  if (part && stop > lp->localL[dir]) return entry_stepwise_blocked(lp, id, slot0);
   std::vector<MugiqHipSpinorField> Elocal;
   const bool ahead = part && lp->halo[id].posted;
   if (!ahead && (st = build_path_links(lp, id, Elocal))) return st;
