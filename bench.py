@@ -246,7 +246,7 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
         tag = "entry_%s%s" % ("+" if e[1] == 1 else "-", names[e[0]])
         ms_f = phase_sum(ph, "entry_fused", i)
         if ms_f > 0:
-            out["roofline"][tag] = roof("fp64_vector", "tile_displaced_contract_kernel" + ("<DIR=0> (row tile)" if e[0] == 0 else " (column tile)"),
+            out["roofline"][tag] = roof("fp64_vector", ("tile16_displaced_contract_kernel<DIR=0> (row tile, 16-line items)" if e[0] == 0 else "tile_displaced_contract_kernel (column tile)"),
                                         ms_f, ent_bytes, ent_flops)
         else:
             ms_i, ms_b = phase_sum(ph, "entry_interior", i), phase_sum(ph, "entry_boundary", i)

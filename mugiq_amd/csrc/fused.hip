@@ -258,6 +258,11 @@ static int launch_fused(FusedArgs<F, A> a, int dir, int sign, hipStream_t stream
   return MUGIQ_HIP_SUCCESS;
 }
 
+// third-generation (16-line tiles, two items per wave), csrc/fused_tile16.hip
+bool tile16_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int precision, int partitioned, bool secondGenerationApplies);
+template <typename F, typename A, int ORDER>
+int tile16_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d, const int *kvals,
+                 int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, int region, hipStream_t stream);
 // second-generation (LDS-tiled) kernel, csrc/fused_tile.hip
 bool tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int precision, int partitioned);
 template <typename F, typename A, int ORDER>
@@ -271,7 +276,10 @@ static int fused_entry(void *loop_d, const MugiqHipSpinorField *ev, const double
   {
     int kmax = 0;
     for (int i = 0; i < nK; i++) kmax = kvals[i] > kmax ? kvals[i] : kmax;
-    if (tile_applicable(ev[0], dir, kmax, ev[0].precision, partitioned))
+    const bool gen2 = tile_applicable(ev[0], dir, kmax, ev[0].precision, partitioned);
+    if (tile16_applicable(ev[0], dir, kmax, ev[0].precision, partitioned, gen2))
+      return tile16_entry<F, A, ORDER>(loop_d, ev, sigma, nVec, E_d, kvals, nK, dir, sign, partitioned, ghost_d, layers, region, stream);
+    if (gen2)
       return tile_entry<F, A, ORDER>(loop_d, ev, sigma, nVec, E_d, kvals, nK, dir, sign, partitioned, ghost_d, layers, region, stream);
   }
   // the streaming kernel has no interior / boundary split: when the dimension is partitioned it counts as boundary
