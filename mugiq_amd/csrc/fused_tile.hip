@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace mugiq {
@@ -66,14 +67,24 @@ template <int ORDER> __device__ inline int64_t comp_offset(int comp, int64_t str
 // accumulators -- at three waves per SIMD a lane has ~168 VGPRs, which 16 fp64 accumulators + W + the prefetch
 // registers do not fit into.  For staging, wave w owns plane w (component 3*spin + colour): its two lane halves fetch
 // alternate positions (32 lanes x 16 B = one 512-byte run each).  PH bounds the positions staged per lane.
-template <typename F, typename A, int ORDER, int DIR, int SIGN, int PH>
+//
+// GLDS (fp64 FLOAT2 storage, column tiles of at most 8 positions): the staged positions go global -> LDS directly
+// (global_load_lds_dwordx4: no stage registers, no ds_write pass) into THREE tile buffers -- one consumed, two in flight.  The
+// transfer wants a lane-linear LDS image, so a buffer is [position pair][12][position & 1][32]: the two lane halves of an
+// instruction (alternate positions, 512 bytes each) land next to each other.
+template <typename F, typename A, int ORDER, int DIR, int SIGN, int PH, bool GLDS>
 __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileArgs<F, A> a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  Cplx<F> *tileBase = reinterpret_cast<Cplx<F> *>(smem);  // 2 x [NP][12][32] (double-buffered over the eigenvectors)
+  Cplx<F> *tileBase = reinterpret_cast<Cplx<F> *>(smem);  // 2 (3: GLDS) x [NP][12][32] (buffered over the eigenvectors)
   const size_t tileElems = (size_t)(2 * PH) * 12 * kTileCols;  // padded to 2*PH positions: commits are unconditional
   const int lane = threadIdx.x & 63;
   const int col = lane & 31, half = lane >> 5;
-  const int wave = threadIdx.x >> 6;
+  const int wave = GLDS ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
+  // element index of (position pp, component, line) inside a tile buffer, and the distance between components
+  constexpr int kCompStride = GLDS ? 2 * kTileCols : kTileCols;
+  auto tileIdx = [&](int pp, int comp, int c) {
+    return GLDS ? (((pp >> 1) * 12 + comp) * 2 + (pp & 1)) * kTileCols + c : (pp * 12 + comp) * kTileCols + c;
+  };
   const bool computes = wave < kTileTJ * a.nslot;
   const int NP = (DIR >= 1) ? kTileTJ + a.kmax : kTileTJ;
   const int J = a.X[DIR];
@@ -227,36 +238,19 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
     asm volatile("" ::: "memory");                       \
   }
 
-// One step: eigenvector n_ is in LDS buffer n_ % 2; `stage` holds eigenvector n_+1 (fetched three steps ago).
-// Commit n_+1 into the other buffer (everyone finished reading it before the barrier that ended the previous step),
-// refill `stage` with n_+4, consume n_, one barrier.  (Little's law: with one workgroup per CU the bytes in flight
-// are what the stage registers hold -- 3 x 42 KB per CU sustains ~6 TB/s at ~4 us loaded latency, 2 x 42 KB does not.)
-#define MUGIQ_TILE_STEP(n_, stage, GUARD)                                                                              \
+// The arithmetic of one eigenvector (scaled by s_) on the tile buffer tile_.
+#define MUGIQ_TILE_COMPUTE(tile_, s_)                                                                                \
   {                                                                                                                    \
-    const Cplx<F> *tile = tileBase + (size_t)((n_) & 1) * tileElems;                                                   \
-    const A s = sigPre;                                                                                                \
-    const Cplx<F> *bodyNow = bodyPre;                                                                                  \
-    { /* table look-ups of the NEXT step, issued first: they complete while this step waits for its staged loads, and  \
-         being scalar loads in flight they would otherwise turn the first LDS wait of the arithmetic into lgkmcnt(0) */ \
-      const int nb_ = (n_) + kDepth + 2 < a.nVec ? (n_) + kDepth + 2 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1; \
-      bodyPre = MUGIQ_TILE_BODY(nb_);                                                                                  \
-      sigPre = MUGIQ_TILE_SIGMA(ns_);                                                                                  \
-    }                                                                                                                  \
-    __builtin_amdgcn_sched_barrier(0); /* keep them first */                                                           \
-    if (GUARD == 0 || (n_) + 1 < a.nVec) {                                                                             \
-      Cplx<F> *nxt = tileBase + (size_t)(((n_) + 1) & 1) * tileElems;                                                  \
-      _Pragma("unroll") for (int i = 0; i < PH; i++)                                                                   \
-        nxt[((2 * i + half) * 12 + wave) * kTileCols + col] = Cplx<F>{stage[i].x, stage[i].y};                         \
-    }                                                                                                                  \
-    if (GUARD == 0 || (n_) + kDepth + 1 < a.nVec) MUGIQ_TILE_FETCH_AT(bodyNow, (n_) + kDepth + 1, stage)               \
+    const Cplx<F> *tile = tile_;                                                                                        \
+    const A s = s_;                                                                                                     \
     if (computes) {                                                                                                    \
-      const Cplx<F> *tl = tile + (ppL * 12) * kTileCols + col;                                                         \
-      const Cplx<F> *ts = tile + (ppS * 12 + half * 6) * kTileCols + colS; /* spins 2*half, 2*half + 1 */              \
+      const Cplx<F> *tl = tile + tileIdx(ppL, 0, col);                                                                 \
+      const Cplx<F> *ts = tile + tileIdx(ppS, half * 6, colS); /* spins 2*half, 2*half + 1 */                          \
       /* t[a2] = s * W * psi[2*half + a2]: each W element and each psi element is read from LDS once */               \
       Cplx<A> t0[3], t1[3];                                                                                            \
       _Pragma("unroll") for (int i = 0; i < 3; i++) t0[i] = t1[i] = Cplx<A>{A(0), A(0)};                               \
       _Pragma("unroll") for (int j = 0; j < 3; j++) {                                                                  \
-        const Cplx<F> w0 = ts[j * kTileCols], w1 = ts[(3 + j) * kTileCols];                                            \
+        const Cplx<F> w0 = ts[j * kCompStride], w1 = ts[(3 + j) * kCompStride];                                            \
         const Cplx<A> p0j{(A)w0.re, (A)w0.im}, p1j{(A)w1.re, (A)w1.im};                                                \
         _Pragma("unroll") for (int i = 0; i < 3; i++) {                                                                \
           const Cplx<A> w = Wr[i * 3 + j];                                                                             \
@@ -271,47 +265,129 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
       _Pragma("unroll") for (int be = 0; be < 4; be++) {                                                               \
         if (be == 2) __builtin_amdgcn_sched_barrier(0); /* bound how many LDS reads the scheduler hoists (VGPRs) */    \
         _Pragma("unroll") for (int c = 0; c < 3; c++) {                                                                \
-          const Cplx<F> u = tl[(be * 3 + c) * kTileCols];                                                              \
+          const Cplx<F> u = tl[(be * 3 + c) * kCompStride];                                                              \
           const Cplx<A> lv{(A)u.re, (A)u.im};                                                                          \
           cmadd_conj(acc[be * 2 + 0], lv, t0[c]);                                                                      \
           cmadd_conj(acc[be * 2 + 1], lv, t1[c]);                                                                      \
         }                                                                                                              \
       }                                                                                                                \
     }                                                                                                                  \
+  }
+
+// One step: eigenvector n_ is in LDS buffer n_ % 2; `stage` holds eigenvector n_+1 (fetched three steps ago).
+// Commit n_+1 into the other buffer (everyone finished reading it before the barrier that ended the previous step),
+// refill `stage` with n_+4, consume n_, one barrier.  (Little's law: with one workgroup per CU the bytes in flight
+// are what the stage registers hold -- 3 x 42 KB per CU sustains ~6 TB/s at ~4 us loaded latency, 2 x 42 KB does not.)
+#define MUGIQ_TILE_STEP(n_, stage, GUARD)                                                                              \
+  {                                                                                                                    \
+    const A sNow = sigPre;                                                                                             \
+    const Cplx<F> *bodyNow = bodyPre;                                                                                  \
+    { /* table look-ups of the NEXT step, issued first: they complete while this step waits for its staged loads, and  \
+         being scalar loads in flight they would otherwise turn the first LDS wait of the arithmetic into lgkmcnt(0) */ \
+      const int nb_ = (n_) + kDepth + 2 < a.nVec ? (n_) + kDepth + 2 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1; \
+      bodyPre = MUGIQ_TILE_BODY(nb_);                                                                                  \
+      sigPre = MUGIQ_TILE_SIGMA(ns_);                                                                                  \
+    }                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0); /* keep them first */                                                           \
+    if (GUARD == 0 || (n_) + 1 < a.nVec) {                                                                             \
+      Cplx<F> *nxt = tileBase + (size_t)(((n_) + 1) & 1) * tileElems;                                                  \
+      _Pragma("unroll") for (int i = 0; i < PH; i++)                                                                   \
+        nxt[((2 * i + half) * 12 + wave) * kTileCols + col] = Cplx<F>{stage[i].x, stage[i].y};                         \
+    }                                                                                                                  \
+    if (GUARD == 0 || (n_) + kDepth + 1 < a.nVec) MUGIQ_TILE_FETCH_AT(bodyNow, (n_) + kDepth + 1, stage)               \
+    MUGIQ_TILE_COMPUTE(tileBase + (size_t)((n_) & 1) * tileElems, sNow)                                                \
     MUGIQ_LDS_BARRIER()                                                                                                \
   }
 
-  // prologue: eigenvector 0 -> LDS buffer 0; eigenvectors 1, 2, 3 in flight in stageA / stageB / stageC
-  MUGIQ_TILE_FETCH(0, stageC)
-#pragma unroll
-  for (int i = 0; i < PH; i++) tileBase[((2 * i + half) * 12 + wave) * kTileCols + col] = Cplx<F>{stageC[i].x, stageC[i].y};
-  // unconditional (clamped) so that the steady-state loop is entered with a KNOWN number of loads in flight: with
-  // conditional prologue loads hipcc's wait-count pass waited for vmcnt(0) at the first commit of every loop iteration,
-  // i.e. for the loads issued one step earlier -- the three-deep prefetch was in effect one deep
-  {
+  if constexpr (GLDS) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (global_load_lds is a device-only builtin: the host pass of hipcc must not see it)
+    typedef __attribute__((address_space(3))) void lds_void;
+    // this lane's share of eigenvector n_ -> tile buffer buf_: PH transfers of 64 x 16 bytes (plane `wave`; the lane halves
+    // carry positions 2 i | 2 i + 1)
+#define MUGIQ_TILE_GLDS(bodyExpr_, n_, buf_)                                                                           \
+  {                                                                                                                    \
+    const Cplx<F> *body_ = bodyExpr_;                                                                                  \
+    const Cplx<F> *gh_ = ghostBase + (int64_t)(n_)*a.ghost_vec_stride;                                                 \
+    Cplx<F> *dst_ = (buf_) + (size_t)wave * 2 * kTileCols;                                                             \
+    _Pragma("unroll") for (int i = 0; i < PH; i++) {                                                                   \
+      const Cplx<F> *ptr_ = (((sghost >> i) & 1u) ? gh_ : body_) + soff[i];                                            \
+      __builtin_amdgcn_global_load_lds(as_global(reinterpret_cast<const vec2 *>(ptr_)),                                \
+                                       (lds_void *)(dst_ + (size_t)i * 24 * kTileCols), 16, 0, 0);                     \
+    }                                                                                                                  \
+  }
+    // One step: eigenvector n_ lands in buffer cur_ (own share: counted vmcnt wait; everybody's: the barrier, which also
+    // says that nobody reads buffer nxt2_ = the one consumed in the previous step any more); eigenvector n_+2 is sent
+    // there, n_+1 stays in flight, n_ is consumed.  One barrier per step, no register staging, no ds_write pass.
+#define MUGIQ_TILE_GSTEP(n_, cur_, nxt2_, STEADY)                                                                      \
+  {                                                                                                                    \
+    const A sNow = sigPre;                                                                                             \
+    const Cplx<F> *bodyNow = bodyPre;                                                                                  \
+    if (STEADY || (n_) + 1 < a.nVec) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PH) : "memory");                         \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
+    MUGIQ_LDS_BARRIER()                                                                                                \
+    if (STEADY || (n_) + 2 < a.nVec) MUGIQ_TILE_GLDS(bodyNow, (n_) + 2, nxt2_)                                         \
+    MUGIQ_TILE_COMPUTE(cur_, sNow)                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    { /* table look-ups of the next step (scalar loads: they complete under the tail of the arithmetic) */            \
+      const int nb_ = (n_) + 3 < a.nVec ? (n_) + 3 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1;      \
+      bodyPre = MUGIQ_TILE_BODY(nb_);                                                                                  \
+      sigPre = MUGIQ_TILE_SIGMA(ns_);                                                                                  \
+    }                                                                                                                  \
+  }
+    Cplx<F> *const buf0 = tileBase, *const buf1 = tileBase + tileElems, *const buf2 = tileBase + 2 * tileElems;
     const int last = a.nVec - 1;
-    MUGIQ_TILE_FETCH((1 < last ? 1 : last), stageA)
-    MUGIQ_TILE_FETCH((2 < last ? 2 : last), stageB)
-    if constexpr (kDepth == 3) MUGIQ_TILE_FETCH((3 < last ? 3 : last), stageC)
-  }
-  const Cplx<F> *bodyPre = MUGIQ_TILE_BODY(a.nVec > kDepth + 1 ? kDepth + 1 : a.nVec - 1);
-  A sigPre = MUGIQ_TILE_SIGMA(0);
-  MUGIQ_LDS_BARRIER()
-  // steady state without any data-dependent branch (hipcc's wait-count pass turns every conditional load into a
-  // conservative `vmcnt(0)`, which would serialise the prefetch), then a guarded tail
-  int n = 0;
-  for (; n + 2 * kDepth < a.nVec; n += kDepth) {
-    MUGIQ_TILE_STEP(n, stageA, 0)
-    MUGIQ_TILE_STEP(n + 1, stageB, 0)
-    if constexpr (kDepth == 3) MUGIQ_TILE_STEP(n + 2, stageC, 0)
-  }
-  for (; n < a.nVec; n += kDepth) {
-    MUGIQ_TILE_STEP(n, stageA, 1)
-    if (n + 1 < a.nVec) MUGIQ_TILE_STEP(n + 1, stageB, 1)
-    if constexpr (kDepth == 3)
-      if (n + 2 < a.nVec) MUGIQ_TILE_STEP(n + 2, stageC, 1)
+    MUGIQ_TILE_GLDS(MUGIQ_TILE_BODY(0), 0, buf0)
+    MUGIQ_TILE_GLDS(MUGIQ_TILE_BODY((1 < last ? 1 : last)), (1 < last ? 1 : last), buf1)  // (unconditional: known count in flight)
+    const Cplx<F> *bodyPre = MUGIQ_TILE_BODY((2 < last ? 2 : last));
+    A sigPre = MUGIQ_TILE_SIGMA(0);
+    int n = 0;
+    for (; n + 4 < a.nVec; n += 3) {
+      MUGIQ_TILE_GSTEP(n, buf0, buf2, 1)
+      MUGIQ_TILE_GSTEP(n + 1, buf1, buf0, 1)
+      MUGIQ_TILE_GSTEP(n + 2, buf2, buf1, 1)
+    }
+    for (; n < a.nVec; n += 3) {  // n % 3 == 0 here
+      MUGIQ_TILE_GSTEP(n, buf0, buf2, 0)
+      if (n + 1 < a.nVec) MUGIQ_TILE_GSTEP(n + 1, buf1, buf0, 0)
+      if (n + 2 < a.nVec) MUGIQ_TILE_GSTEP(n + 2, buf2, buf1, 0)
+    }
+#undef MUGIQ_TILE_GSTEP
+#undef MUGIQ_TILE_GLDS
+#endif
+  } else {
+    // prologue: eigenvector 0 -> LDS buffer 0; eigenvectors 1, 2, 3 in flight in stageA / stageB / stageC
+    MUGIQ_TILE_FETCH(0, stageC)
+#pragma unroll
+    for (int i = 0; i < PH; i++) tileBase[((2 * i + half) * 12 + wave) * kTileCols + col] = Cplx<F>{stageC[i].x, stageC[i].y};
+    // unconditional (clamped) so that the steady-state loop is entered with a KNOWN number of loads in flight: with
+    // conditional prologue loads hipcc's wait-count pass waited for vmcnt(0) at the first commit of every loop iteration,
+    // i.e. for the loads issued one step earlier -- the three-deep prefetch was in effect one deep
+    {
+      const int last = a.nVec - 1;
+      MUGIQ_TILE_FETCH((1 < last ? 1 : last), stageA)
+      MUGIQ_TILE_FETCH((2 < last ? 2 : last), stageB)
+      if constexpr (kDepth == 3) MUGIQ_TILE_FETCH((3 < last ? 3 : last), stageC)
+    }
+    const Cplx<F> *bodyPre = MUGIQ_TILE_BODY(a.nVec > kDepth + 1 ? kDepth + 1 : a.nVec - 1);
+    A sigPre = MUGIQ_TILE_SIGMA(0);
+    MUGIQ_LDS_BARRIER()
+    // steady state without any data-dependent branch (hipcc's wait-count pass turns every conditional load into a
+    // conservative `vmcnt(0)`, which would serialise the prefetch), then a guarded tail
+    int n = 0;
+    for (; n + 2 * kDepth < a.nVec; n += kDepth) {
+      MUGIQ_TILE_STEP(n, stageA, 0)
+      MUGIQ_TILE_STEP(n + 1, stageB, 0)
+      if constexpr (kDepth == 3) MUGIQ_TILE_STEP(n + 2, stageC, 0)
+    }
+    for (; n < a.nVec; n += kDepth) {
+      MUGIQ_TILE_STEP(n, stageA, 1)
+      if (n + 1 < a.nVec) MUGIQ_TILE_STEP(n + 1, stageB, 1)
+      if constexpr (kDepth == 3)
+        if (n + 2 < a.nVec) MUGIQ_TILE_STEP(n + 2, stageC, 1)
+    }
   }
 #undef MUGIQ_TILE_STEP
+#undef MUGIQ_TILE_COMPUTE
   // ---- epilogue: the two lane halves of a wave hold complementary halves of the 4x4 colour-traced spin matrix of the
   // same 32 sites.  Exchange them with wavefront shuffles (lane ^ 32), then each half takes 8 of the 16 gamma traces.
   if (computes) {
@@ -345,8 +421,11 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
 template <typename F, typename A, int ORDER> static int launch_tile(TileArgs<F, A> a, int dir, int sign, hipStream_t stream) {
   const int NP = dir >= 1 ? kTileTJ + a.kmax : kTileTJ;
   const int PHsel = NP <= 8 ? 4 : kTileMaxPos / 2;
-  const size_t tileBytes = 2 * sizeof(Cplx<F>) * (size_t)(2 * PHsel) * 12 * kTileCols;  // two buffers, padded positions
-  const size_t shmem = tileBytes;  // the two staging tiles
+  // global -> LDS staging with three buffers: fp64 FLOAT2 column tiles of at most 8 positions (MUGIQ_HIP_TILE_GLDS=0: off)
+  bool glds = std::is_same<F, double>::value && ORDER == 2 && dir >= 1 && NP <= 8;
+  if (const char *e = getenv("MUGIQ_HIP_TILE_GLDS")) glds = glds && atoi(e) != 0;
+  const size_t tileBytes = (glds ? 3 : 2) * sizeof(Cplx<F>) * (size_t)(2 * PHsel) * 12 * kTileCols;  // padded positions
+  const size_t shmem = tileBytes;  // the staging tiles
   a.tileBytes = (int)tileBytes;
   unsigned nblocks = ((a.numCols + kTileCols - 1) / kTileCols) * a.jtCount;
   if (dir == 0) {  // row tile: 2 groups of kTileCols/(X0/2) whole x-rows per workgroup
@@ -359,16 +438,22 @@ template <typename F, typename A, int ORDER> static int launch_tile(TileArgs<F, 
   if (const char *e = getenv("MUGIQ_HIP_TILE_ORDER")) a.blockOrder = atoi(e) & 3;
   if (nblocks % 8 != 0) a.blockOrder &= 1;
   const dim3 grid(nblocks), block(64 * 12);
-#define MUGIQ_TILE_LAUNCH(D, S, P)                                                                                    \
+#define MUGIQ_TILE_LAUNCH(D, S, P, G)                                                                                 \
   {                                                                                                                   \
-    auto kern = tile_displaced_contract_kernel<F, A, ORDER, D, S, P>;                                                 \
+    auto kern = tile_displaced_contract_kernel<F, A, ORDER, D, S, P, G>;                                              \
     if (shmem > 64 * 1024)                                                                                            \
       MUGIQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, a);                                                          \
   }
 #define MUGIQ_TILE_CASE(D, S)                                                                                         \
   case (D)*2 + (S):                                                                                                   \
-    if (NP <= 8) MUGIQ_TILE_LAUNCH(D, S, 4) else MUGIQ_TILE_LAUNCH(D, S, kTileMaxPos / 2)                             \
+    if constexpr (std::is_same<F, double>::value && ORDER == 2 && (D) >= 1) {                                         \
+      if (glds) {                                                                                                     \
+        MUGIQ_TILE_LAUNCH(D, S, 4, true)                                                                              \
+        break;                                                                                                        \
+      }                                                                                                               \
+    }                                                                                                                 \
+    if (NP <= 8) MUGIQ_TILE_LAUNCH(D, S, 4, false) else MUGIQ_TILE_LAUNCH(D, S, kTileMaxPos / 2, false)               \
     break;
   switch (dir * 2 + sign) {
     MUGIQ_TILE_CASE(0, 0) MUGIQ_TILE_CASE(0, 1) MUGIQ_TILE_CASE(1, 0) MUGIQ_TILE_CASE(1, 1)
