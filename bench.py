@@ -63,6 +63,7 @@ def parse():
                     help="only the headline (use this under `rocprofv3 --stats`: the extra legs launch the headline kernel with "
                          "other shapes and would blur its per-kernel average)")
     ap.add_argument("--extra", default="", help="comma list restricting the extra legs: displaced,mg,cfg3 (N=1) / partitioned (N>1)")
+    ap.add_argument("--displaced-nev", type=int, default=100, help="eigenvectors of the displaced extra leg (configs[2] has 400: 102 GB)")
     ap.add_argument("--extra-timeout", type=float, default=420.0, help="watchdog for the extra legs (s); the headline line is printed anyway")
     # overrides of the partitioned leg (rehearsals on a one-GPU box: MUGIQ_BENCH_BACKEND=gloo and a small lattice)
     ap.add_argument("--part-lattice", type=int, nargs=4, default=None, help="LOCAL lattice of the partitioned leg")
@@ -279,10 +280,11 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
     return out
 
 
-def extra_displaced(hip, device):
-    X, nev = (48, 48, 24, 24), 100
+def extra_displaced(hip, device, nev=100):
+    X = (48, 48, 24, 24)
     out = displaced_job(hip, device, X, nev, 8, None, 1)
-    out["workload"] = "48x48x24x24 fp64 N_ev=%d (configs[2] per-GPU lattice, N_ev reduced from 400), entries %s, momentum projection p^2<=9, driver OPT plan" % (nev, ENTRIES_CFG2)
+    out["workload"] = "48x48x24x24 fp64 N_ev=%d (configs[2] per-GPU lattice%s), entries %s, momentum projection p^2<=9, driver OPT plan" % (
+        nev, "" if nev == 400 else ", N_ev reduced from 400", ENTRIES_CFG2)
     return out
 
 
@@ -485,7 +487,7 @@ def main():
         del fields, big, loop
         torch.cuda.empty_cache()
         want = [w for w in a.extra.split(",") if w]
-        legs = ([("displaced_loops", "displaced", lambda: extra_displaced(hip, device)),
+        legs = ([("displaced_loops", "displaced", lambda: extra_displaced(hip, device, a.displaced_nev)),
                  ("mg_coarse_loop", "mg", lambda: extra_mg(hip, device)),
                  ("cfg3_mixed_precision_ultra_local", "cfg3", lambda: extra_cfg3(hip, device))] if world == 1 else
                 [("partitioned_displaced_loops", "partitioned", lambda: extra_partitioned(hip, device, a, world, rank, backend))])
