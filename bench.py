@@ -42,6 +42,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CLOCK_NOTE = ("peak = 78.6 TFLOP/s at 2.4 GHz; the device runs the tiled displaced kernels at 1.72-1.78 GHz (GRBM_GUI_ACTIVE / duration, "
+              "profiles/r02_kernel_clocks.txt): 56.7 TFLOP/s on offer at that clock")
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # same guide: FP32 vector 157.3 TFLOP/s; fp64 FMA (vector and MFMA alike) runs at half of it
 ENTRIES_CFG2 = "+x:1,3;-x:1,3;+y:1,3;-y:1,3;+z:1,3;-z:1,3;+t:1,3;-t:1,3"
 
@@ -195,6 +197,39 @@ def source_fingerprint():
     return h.hexdigest()[:12]
 
 
+def library_fingerprint():
+    """sha1 over every source of libmugiq_hip.so (tools/pmc_traffic_extra.py records the same)"""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "mugiq_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+_EXTRA_TRAFFIC = None
+
+
+def attach_traffic(block, substrings, grid=None):
+    """HBM bytes per launch of a kernel of the extra legs from the committed PMC passes (profiles/traffic_extra_latest.json),
+    attached only when they were taken with the library sources of this run; otherwise the block keeps traffic = null."""
+    global _EXTRA_TRAFFIC
+    if _EXTRA_TRAFFIC is None:
+        _EXTRA_TRAFFIC = {}
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_extra_latest.json")))
+            if tj.get("library_fingerprint") == library_fingerprint():
+                _EXTRA_TRAFFIC = tj
+        except (OSError, ValueError):
+            pass
+    for k in _EXTRA_TRAFFIC.get("kernels", []):
+        if all(x in k["name"] for x in substrings) and (grid is None or k["grid"] == grid):
+            block["traffic"] = k["hbm_bytes_per_launch"]
+            block["traffic_source"] = "profiles/traffic_extra_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, library sources %s)" % _EXTRA_TRAFFIC["library_fingerprint"]
+            break
+    return block
+
+
 def phase_sum(phases, kind, entry=None):
     return sum(p["ms"] for p in phases if p["kind"] == kind and (entry is None or p["entry"] == entry))
 
@@ -236,6 +271,7 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
             best = rec
     ph = best["phases"]
     nslot = 3
+    pmc_workload = comm is None and tuple(X) == (48, 48, 24, 24) and nev == 100 and prec == 8   # what the committed PMC passes ran
     ent_bytes = V * (nev * 24 * B + nslot * (24 * B + 32 * B))                 # eigenvectors once + W_k once + slots written once
     ent_flops = V * nev * nslot * (36 + 48) * 8.0                               # SU(3) x spinor + colour-traced outer product, complex FMAs
     out = {"seconds": best["seconds"], "sites_per_s_all_slots": world * V / best["seconds"], "n_loop_slots": best["nLoop"],
@@ -248,7 +284,9 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
         ms_f = phase_sum(ph, "entry_fused", i)
         if ms_f > 0:
             out["roofline"][tag] = roof("fp64_vector", ("tile16_displaced_contract_kernel<DIR=0> (row tile, 16-line items)" if e[0] == 0 else "tile_displaced_contract_kernel (column tile)"),
-                                        ms_f, ent_bytes, ent_flops)
+                                        ms_f, ent_bytes, ent_flops, note=CLOCK_NOTE)
+            if pmc_workload:
+                attach_traffic(out["roofline"][tag], ["displaced_contract_kernel<double, double, 2, %d, %d," % (e[0], e[1])])
         else:
             ms_i, ms_b = phase_sum(ph, "entry_interior", i), phase_sum(ph, "entry_boundary", i)
             out["roofline"][tag] = roof("fp64_vector", "tile_displaced_contract_kernel interior + boundary (partitioned axis)",
@@ -256,6 +294,8 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
             out["roofline"][tag].update({"interior_ms": ms_i, "boundary_ms": ms_b, "halo_wait_ms": phase_sum(ph, "halo_wait", i)})
     ms_u = phase_sum(ph, "ultra_local")
     out["roofline"]["ultra_local"] = roof("hbm", "loop_contract_kernel", ms_u, V * (nev * 24 * B + 32 * B))
+    if pmc_workload:
+        attach_traffic(out["roofline"]["ultra_local"], ["loop_contract_kernel"], V)
     ms_r = phase_sum(ph, "entry_reflected")
     nref = sum(3 for d in best["derived"] if d >= 0)
     if nref:
@@ -268,6 +308,10 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
                                                   note="algorithmic bytes = the position-space buffer read once + the x-summed array (%d distinct p_x of "
                                                        "%d momenta, 1/%d of the input per p_x) written once; the y and z steps work on arrays Lx and Lx*Ly "
                                                        "times smaller and are counted in the time only" % (npx, len(moms), X[0]))
+    if pmc_workload and "momentum_projection" in out["roofline"]:
+        attach_traffic(out["roofline"]["momentum_projection"], ["eo_dft_x"])
+        if out["roofline"]["momentum_projection"].get("traffic"):
+            out["roofline"]["momentum_projection"]["traffic_note"] = "eo_dft_x only (the y and z steps move 1.3 GB more)"
     out["momentum_copy_ms"] = phase_sum(ph, "momentum_copy")
     out["momentum_reduce_host_ms"] = phase_sum(ph, "momentum_reduce")
     halo = [p for p in ph if p["kind"] == "halo_transfer"]
@@ -318,11 +362,16 @@ def extra_mg(hip, device):
     volc = V // 256
     flops = 8.0 * (volc * nev * NC * NC + V * (12 * NC * nvec + 48 * nvec))
     byts = V * 12 * nvec * 16 + nev * volc * NC * 16 + V * 32 * 8
-    return {"workload": "32x32x32x32 fp64 MG coarse path: n_vec=24, 4^4 aggregates, N_ev=200 coarse eigenvectors, ultra-local loop (configs[4])",
+    res = {"workload": "32x32x32x32 fp64 MG coarse path: n_vec=24, 4^4 aggregates, N_ev=200 coarse eigenvectors, ultra-local loop (configs[4])",
             "kernel_ms": best, "sites_per_s": V / (best * 1e-3),
             "roofline": roof("fp64_vector", "coarse_outer_kernel + fine_congruence_kernel", best, byts, flops,
                              note="flops of the coarse-grid plan actually executed (outer product on the coarse grid + V C V^dag per fine "
                                   "site), not of the per-eigenvector prolongation it replaces (8*12*n_vec*V*N_ev = %.0f GFLOP)" % (8.0 * 12 * nvec * V * nev / 1e9))}
+    a1, a2 = attach_traffic({}, ["coarse_outer_kernel"]), attach_traffic({}, ["fine_congruence"])
+    if a1.get("traffic") and a2.get("traffic"):
+        res["roofline"]["traffic"] = a1["traffic"] + a2["traffic"]
+        res["roofline"]["traffic_source"] = a2["traffic_source"]
+    return res
 
 
 def extra_cfg3(hip, device):
