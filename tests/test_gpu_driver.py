@@ -409,13 +409,16 @@ def test_driver_mg_coarse_path_random(hip, seed, record_max):
 
 
 @pytest.mark.parametrize("X", [(4, 8, 4, 8), (8, 4, 4, 8), (6, 4, 12, 4), (16, 4, 4, 4), (12, 8, 4, 4)])
-@pytest.mark.parametrize("tile", ["0", "1", "cols16", "cols32"])
+@pytest.mark.parametrize("tile", ["0", "1", "cols16", "cols32", "regs"])
 def test_fused_plans_agree_tiled_and_streaming(hip, tile, X, monkeypatch):
     """The LDS-tiled kernels (csrc/fused_tile.hip: 32-line positions; csrc/fused_tile16.hip: 16-line items, by default only
     for x rows that do not fill 32-line positions) and the first-generation streaming kernel are implementations of the same
-    entry point: each must match the oracle.  cols16 / cols32 force one tiled generation for everything it can take."""
+    entry point: each must match the oracle.  cols16 / cols32 force one tiled generation for everything it can take; regs
+    stages the fp64 column tiles through registers instead of global -> LDS transfers (MUGIQ_HIP_TILE_GLDS=0)."""
     if tile.startswith("cols"):
         monkeypatch.setenv("MUGIQ_HIP_TILE_COLS", tile[4:])
+    elif tile == "regs":
+        monkeypatch.setenv("MUGIQ_HIP_TILE_GLDS", "0")
     else:
         monkeypatch.setenv("MUGIQ_HIP_FUSED_TILE", tile)
     nev = 3
@@ -464,10 +467,15 @@ def test_driver_random_shapes_both_fused_plans(hip, seed, monkeypatch, record_ma
                                             orc.phase_matrix(moms, locV3, FTSign, X, X), X[3], cprm.nData, locV3, len(moms))
     tol = 1e-12 if prec == 8 else 1e-5                                  # north_star: 1e-12 fp64 / 1e-5 fp32
     tag = "fp64" if prec == 8 else "fp32"
-    for tile in ("1", "0", "cols16"):
+    for tile in ("1", "0", "cols16") + (("regs",) if prec == 8 and order == 2 else ()):
+        monkeypatch.delenv("MUGIQ_HIP_TILE_GLDS", raising=False)
         if tile == "cols16":
             monkeypatch.setenv("MUGIQ_HIP_FUSED_TILE", "1")
             monkeypatch.setenv("MUGIQ_HIP_TILE_COLS", "16")
+        elif tile == "regs":
+            monkeypatch.delenv("MUGIQ_HIP_TILE_COLS", raising=False)
+            monkeypatch.setenv("MUGIQ_HIP_FUSED_TILE", "1")
+            monkeypatch.setenv("MUGIQ_HIP_TILE_GLDS", "0")
         else:
             monkeypatch.delenv("MUGIQ_HIP_TILE_COLS", raising=False)
             monkeypatch.setenv("MUGIQ_HIP_FUSED_TILE", tile)
