@@ -367,6 +367,22 @@ typedef struct MugiqHipComm_s {
   int (*group_end)(void *ctx, void *stream);
 } MugiqHipComm;
 
+/* exchangeGhostVec(ColorSpinorField *x), lib/contract_wrappers.cu:166-169 (x->exchangeGhost(QUDA_INVALID_PARITY, nFace = 1, 0)):
+ * fill the depth-1 ghost zones v->ghost[d][0 | 1] of every partitioned dimension (comm->grid[d] > 1), both directions,
+ * through comm->sendrecv (one transfer group when the transport has group_begin / group_end).  The zones must be device
+ * buffers of 2*12*faceCB complex each; comm == NULL (one process) is a no-op.  The faces are packed into the library's
+ * per-stream workspace. */
+int mugiq_hip_exchange_ghost_vec(const MugiqHipSpinorField *v, const MugiqHipComm *comm, void *stream);
+
+/* What Displace asks of QUDA's ColorSpinorField for its auxiliary vector (lib/displace.cpp:26-30: ColorSpinorField::Create
+ * with QUDA_ZERO_FIELD_CREATE and setPrecision(coarsePrec_); :42,:50-51: operator=; :59: blas::zero), for hosts that do not
+ * manage device memory themselves.  alloc: geometry, order, stride of `like`, `precision` (0 = like's), zeroed; ghost zones
+ * (zeroed) for the dims with ghostDims[d] != 0 (NULL = none).  copy: same precision / order / geometry required. */
+int mugiq_hip_alloc_spinor_like(MugiqHipSpinorField *out, const MugiqHipSpinorField *like, int precision, const int ghostDims[4]);
+int mugiq_hip_free_spinor(MugiqHipSpinorField *f);
+int mugiq_hip_copy_spinor(const MugiqHipSpinorField *dst, const MugiqHipSpinorField *src, void *stream);
+int mugiq_hip_zero_spinor(const MugiqHipSpinorField *f, void *stream);
+
 /* MugiqLoopParam (include/mugiq.h:28-47) with C arrays instead of std::vector/std::string.
  * gauge: the reference hands over host QDP-ordered links + a QudaGaugeParam and lets Displace build the
  * border-extended device field (lib/displace.cpp:104-134); here the extended device field is the input

@@ -194,6 +194,99 @@ inline void setDisplaceEntryString(MugiqLoopParam &p, const std::string &entries
   p.doNonLocal = MUGIQ_BOOL_TRUE;
 }
 
+// lib/contract_wrappers.cu:166-169: depth-1 ghost zones of every partitioned dimension, both directions
+inline void exchangeGhostVec(ColorSpinorField *x, const MugiqHipComm *comm = nullptr, void *stream = nullptr) {
+  check(mugiq_hip_exchange_ghost_vec(x, comm, stream));
+}
+
+// include/displace.h:13-80, lib/displace.cpp: the displacement state machine Loop_Mugiq drives (its friend in the reference;
+// public here so that the reference's loop nest, lib/loop_mugiq.cpp:455-509, can be written against it call for call).
+// `comm` stands for QUDA's communicator (commDimPartitioned), NULL = one process.
+template <typename Float, int fieldOrder> class Displace {
+  const std::vector<std::string> DisplaceFlagArray{"+x", "-x", "+y", "-y", "+z", "-z", "+t", "-t"};  // include/displace.h:21
+  const char *DisplaceDirArray[4] = {"x", "y", "z", "t"};
+  const char *DisplaceSignArray[2] = {"-", "+"};
+  std::string dispString;
+  DisplaceFlag dispFlag = DispFlagNone;
+  DisplaceDir dispDir = DispDirNone;
+  DisplaceSign dispSign = DispSignNone;
+  GaugeField ownGauge_{};            // gaugeField when built here from loopParams.gauge[4]
+  const GaugeField *gaugeField = nullptr;
+  ColorSpinorField auxDispVec{};
+  const MugiqHipComm *comm_;
+  void *stream_;
+  int commDim_[4], exRng[4];
+
+public:
+  Displace(MugiqLoopParam *lp, const ColorSpinorField *csf, int coarsePrec = 0, const MugiqHipComm *comm = nullptr, void *stream = nullptr)
+      : comm_(comm), stream_(stream) {
+    checkField<Float, fieldOrder>(csf, "Displace");
+    for (int d = 0; d < 4; d++) {
+      commDim_[d] = (comm && comm->grid[d] > 1) ? 1 : 0;
+      exRng[d] = 2 * commDim_[d];  // lib/displace.cpp:16
+    }
+    if (lp->gauge_ext) gaugeField = lp->gauge_ext;
+    else {
+      if (!lp->gauge[0] || !lp->gauge_param) throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "Displace: loopParams holds no gauge field");
+      const GaugeParam &gp = *lp->gauge_param;
+      if ((int)gp.cuda_prec != precisionOf<Float>())
+        throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "createCudaGaugeField: Incompatible precision settings between Displace template and gauge field parameters");
+      int X[4];
+      for (int d = 0; d < 4; d++) X[d] = gp.X[d];
+      check(mugiq_hip_alloc_extended_gauge(&ownGauge_, X, exRng, precisionOf<Float>()));
+      const void *links[4] = {lp->gauge[0], lp->gauge[1], lp->gauge[2], lp->gauge[3]};
+      const int st = mugiq_hip_create_extended_gauge(&ownGauge_, links, (int)gp.cpu_prec, comm, stream);
+      if (st) {
+        mugiq_hip_free_extended_gauge(&ownGauge_);
+        check(st);
+      }
+      gaugeField = &ownGauge_;
+    }
+    check(mugiq_hip_alloc_spinor_like(&auxDispVec, csf, coarsePrec, nullptr));  // QUDA_ZERO_FIELD_CREATE, lib/displace.cpp:26-30
+  }
+  ~Displace() {
+    mugiq_hip_free_spinor(&auxDispVec);
+    if (ownGauge_.data) mugiq_hip_free_extended_gauge(&ownGauge_);
+  }
+  Displace(const Displace &) = delete;
+  Displace &operator=(const Displace &) = delete;
+
+  // lib/displace.cpp:137-152
+  DisplaceFlag WhichDisplaceFlag() const {
+    for (int i = 0; i < (int)DisplaceFlagArray.size(); i++)
+      if (dispString == DisplaceFlagArray[i]) return static_cast<DisplaceFlag>(i);
+    throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "WhichDisplaceFlag: Cannot parse given displacement string = " + dispString + ".");
+  }
+  DisplaceDir WhichDisplaceDir() const { return static_cast<DisplaceDir>((int)dispFlag / 2); }                          // :155-180
+  DisplaceSign WhichDisplaceSign() const { return ((int)dispFlag % 2 == 0) ? DispSignPlus : DispSignMinus; }           // :182-203
+  // lib/displace.cpp:206-223
+  void setupDisplacement(const std::string &dStr) {
+    dispString = dStr;
+    dispFlag = WhichDisplaceFlag();
+    dispDir = WhichDisplaceDir();
+    dispSign = WhichDisplaceSign();
+    int d = -1, sg = -1;
+    check(mugiq_hip_parse_displacement(dStr.c_str(), &d, &sg));  // the library's table must agree
+    if (d != (int)dispDir || sg != (int)dispSign) throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "setupDisplacement: Got invalid dispDir and/or dispSign.");
+  }
+  DisplaceDir dir() const { return dispDir; }
+  DisplaceSign sign() const { return dispSign; }
+  const GaugeField *gauge() const { return gaugeField; }
+  // lib/displace.cpp:40-52
+  void resetAuxDispVec(const ColorSpinorField *fineEvec) { check(mugiq_hip_copy_spinor(&auxDispVec, fineEvec, stream_)); }
+  void swapAuxDispVec(ColorSpinorField *displacedEvec) { check(mugiq_hip_copy_spinor(displacedEvec, &auxDispVec, stream_)); }
+  // lib/displace.cpp:55-67 (+ the exchangeGhostVec of lib/contract_wrappers.cu:178): displacedEvec <- D_{dir,sign} displacedEvec
+  void doVectorDisplacement(DisplaceType dispType, ColorSpinorField *displacedEvec, int /*idisp*/) {
+    if (dispType != DISPLACE_TYPE_COVARIANT) throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "Unsupported Displacement type " + std::to_string((int)dispType));
+    if (dispDir == DispDirNone) throw Error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "doVectorDisplacement: Got invalid dispDir and/or dispSign.");
+    check(mugiq_hip_zero_spinor(&auxDispVec, stream_));
+    exchangeGhostVec(displacedEvec, comm_, stream_);
+    ColorSpinorField aux = auxDispVec;
+    performCovariantDisplacementVector<Float, fieldOrder>(&aux, displacedEvec, const_cast<GaugeField *>(gaugeField), dispDir, dispSign, commDim_, stream_);
+    swapAuxDispVec(displacedEvec);
+  }
+};
+
 // include/loop_mugiq.h:123-134: Loop_Mugiq(loopParams, eigsolve); computeCoarseLoop(); writeLoopsHDF5()
 // `eVecs` / `eVals_sigma` are what the reference reads from Eigsolve_Mugiq as a friend (lib/loop_mugiq.cpp:442,479).
 template <typename Float, int fieldOrder> class Loop_Mugiq {

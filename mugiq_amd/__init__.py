@@ -10,7 +10,7 @@ _lib.load()
 from .fields import SpinorField, GaugeField, CoarseField, Transfer, FLOAT2, FLOAT4  # noqa: E402
 from .operators import (  # noqa: E402
     copyGammaCoeffStructToSymbol, copyGammaMapStructToSymbol, gammaTables, GammaName,
-    performLoopContraction, performLoopContractionBatched, performCovariantDisplacementVector, packFace,
+    performLoopContraction, performLoopContractionBatched, performCovariantDisplacementVector, packFace, exchangeGhostVec,
     createPhaseMatrixGPU, convertIdxOrder_mapGamma, momentumProjection, momentumProjectionSeparable, convertAndProject, packFaceLayers, displacedLoopContractionFused, reflectDisplacedLoop, packLoopLayers, probeReadBandwidth, prolongateEvecs, prolongateCoarseEvecs, prolongateContractBatched,
     DispDir, DispSignMinus, DispSignPlus, LOOP_FT_SIGN_MINUS, LOOP_FT_SIGN_PLUS, DisplaceFlagArray,
 )
@@ -20,5 +20,6 @@ from .loop import (  # noqa: E402
     LOOP_CALC_TYPE_BLAS, LOOP_CALC_TYPE_OPT_KERNEL, LOOP_CALC_TYPE_BASIC_KERNEL,
 )
 from .comm import GridComm  # noqa: E402
+from .displace import Displace, DISPLACE_TYPE_COVARIANT  # noqa: E402
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -82,6 +82,11 @@ SIGNATURES = {
     "mugiq_hip_perform_covariant_displacement_vector": (ctypes.c_int, [_SP, _SP, _GP, ctypes.c_int, ctypes.c_int,
                                                                        _I4, _VP]),
     "mugiq_hip_pack_face": (ctypes.c_int, [_VP, _SP, ctypes.c_int, ctypes.c_int, _VP]),
+    "mugiq_hip_exchange_ghost_vec": (ctypes.c_int, [_SP, _VP, _VP]),
+    "mugiq_hip_alloc_spinor_like": (ctypes.c_int, [_SP, _SP, ctypes.c_int, _I4]),
+    "mugiq_hip_free_spinor": (ctypes.c_int, [_SP]),
+    "mugiq_hip_copy_spinor": (ctypes.c_int, [_SP, _SP, _VP]),
+    "mugiq_hip_zero_spinor": (ctypes.c_int, [_SP, _VP]),
     "mugiq_hip_create_phase_matrix": (ctypes.c_int, [_VP, _I4, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
                                                      _I4, _I4, _I4, ctypes.c_int, _VP]),
     "mugiq_hip_convert_idx_order_map_gamma": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -89,6 +89,19 @@ def performCovariantDisplacementVector(dst, src, gauge, dispDir, dispSign, commD
         ctypes.byref(dd), ctypes.byref(ds), ctypes.byref(dg), int(dispDir), int(dispSign), _lib.int4(commDim), _stream()))
 
 
+def exchangeGhostVec(x, comm):
+    """exchangeGhostVec(ColorSpinorField *x)                       lib/contract_wrappers.cu:166-169
+    depth-1 ghost zones of every partitioned dimension, both directions, through `comm` (a GridComm; None = one process)."""
+    if comm is None:
+        return
+    for d in range(4):
+        if comm.comm_dim_partitioned(d):
+            x.alloc_ghost(d, 0), x.alloc_ghost(d, 1)
+    dx, c = x.desc(), comm.c_struct()
+    _lib.check(_lib.load().mugiq_hip_exchange_ghost_vec(ctypes.byref(dx), ctypes.cast(ctypes.byref(c), ctypes.c_void_p), _stream()))
+    torch.cuda.current_stream().synchronize()
+
+
 def packFace(face_d, src, dim, high):
     """Send half of exchangeGhostVec: face of `src` in ghost-zone layout (see mugiq_hip_pack_face)."""
     ds = src.desc()

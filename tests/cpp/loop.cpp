@@ -130,6 +130,51 @@ int main(int argc, char **argv) {
       for (int n = 0; n < nev; n++) expect += 1.0 / sigma[n];
       printf("ultra-local max rel err vs C oracle: %.3e ; sum_x L_1(x) = %.12e (expected %.12e)\n", err / mx, s1, expect);
       if (err / mx > 1e-12 || std::abs(s1 - expect) > 1e-10 * expect) rc = 1;
+      if (lp.doNonLocal == MUGIQ_BOOL_TRUE && !lp.disp_str.empty()) {
+        // the loop nest of Loop_Mugiq::computeCoarseLoop (lib/loop_mugiq.cpp:455-509) call for call through the operator API:
+        // Displace::setupDisplacement / doVectorDisplacement + performLoopContraction -- every slot must equal the driver's
+        const size_t perLoop = (size_t)16 * V;
+        cplx *nest_d = nullptr;
+        HIPCHK(hipMalloc(&nest_d, perLoop * info.nLoop * sizeof(cplx)));
+        HIPCHK(hipMemset(nest_d, 0, perLoop * info.nLoop * sizeof(cplx)));
+        Displace<double, FLOAT2_FIELD_ORDER> displace(&lp, &eVecs[0], 8);
+        ColorSpinorField fineEvecL{}, fineEvecR{};
+        mugiq_hip::check(mugiq_hip_alloc_spinor_like(&fineEvecL, &eVecs[0], 0, nullptr));
+        mugiq_hip::check(mugiq_hip_alloc_spinor_like(&fineEvecR, &eVecs[0], 0, nullptr));
+        for (int id = -1; id < (int)lp.disp_str.size(); id++) {
+          int e6[6] = {0, 0, 0, 0, 1, 0};
+          if (id != -1) {
+            displace.setupDisplacement(lp.disp_str[id]);
+            mugiq_hip::check(mugiq_hip_loop_get_entry(loop.handle(), id, e6));
+          }
+          const size_t bufOffset = id == -1 ? 0 : perLoop * e6[5];
+          for (int n = 0; n < nev; n++) {
+            mugiq_hip::check(mugiq_hip_copy_spinor(&fineEvecL, &eVecs[n], nullptr));
+            mugiq_hip::check(mugiq_hip_copy_spinor(&fineEvecR, &fineEvecL, nullptr));
+            if (id == -1) {
+              performLoopContraction<double, FLOAT2_FIELD_ORDER>(nest_d, &fineEvecL, &fineEvecR, sigma[n]);
+              continue;
+            }
+            int dispCount = 0;
+            for (int idisp = 1; idisp <= e6[3]; idisp++) {
+              displace.doVectorDisplacement(DISPLACE_TYPE_COVARIANT, &fineEvecR, idisp);
+              if (idisp >= e6[2] && idisp <= e6[3]) {
+                performLoopContraction<double, FLOAT2_FIELD_ORDER>(nest_d + bufOffset + perLoop * dispCount, &fineEvecL, &fineEvecR, sigma[n]);
+                dispCount++;
+              }
+            }
+          }
+        }
+        std::vector<cplx> nest(perLoop * info.nLoop);
+        HIPCHK(hipMemcpy(nest.data(), nest_d, nest.size() * sizeof(cplx), hipMemcpyDeviceToHost));
+        double nerr = 0, nmx = 0;
+        for (size_t i = 0; i < nest.size(); i++) { nerr = std::max(nerr, std::abs(nest[i] - pos[i])); nmx = std::max(nmx, std::abs(nest[i])); }
+        printf("reference loop nest through Displace + performLoopContraction vs the driver, %d slots: max rel diff %.3e\n", info.nLoop, nerr / nmx);
+        if (!(nerr / nmx < 1e-12)) rc = 1;
+        mugiq_hip_free_spinor(&fineEvecL);
+        mugiq_hip_free_spinor(&fineEvecR);
+        (void)hipFree(nest_d);
+      }
       if (lp.doMomProj == MUGIQ_BOOL_TRUE) {  // p = 0 of the g5 channel (output slot 15 <- T(0), sign +) = sum over space of L_1
         for (int im = 0; im < info.Nmom; im++)
           if (lp.momMatrix[im][0] == 0 && lp.momMatrix[im][1] == 0 && lp.momMatrix[im][2] == 0) {

@@ -159,6 +159,28 @@ def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8), 
     _check_pos(orc, comm.coord, grid, G, l, cprm, loop.dataPos_d.cpu().numpy().astype(np.complex128), pos_g, tol)
     e = rel_err(loop.dataMom_global(), mom_g)
     assert e < tol, ("dataMom", e)
+    if seed is None and calc_type == hip.LOOP_CALC_TYPE_BASIC_KERNEL:
+        # the reference's own nest for two entries, call for call through the Displace mirror (its exchangeGhostVec goes through
+        # `comm`, its extended gauge is built from the host QDP links): same slots as the driver's
+        from types import SimpleNamespace
+        got = loop.dataPos_d.clone()
+        displace = hip.Displace(SimpleNamespace(gauge=None, gauge_qdp=orc.gauge_to_qdp_host(U_loc)), f[0], prec, comm)
+        per = 16 * int(np.prod(l))
+        R = hip.SpinorField(l, prec, order)
+        for idx in (0, 3):                                                  # "+t": 1..3 and "-z": 1
+            displace.setupDisplacement(disp[0][idx])
+            mine = torch.zeros(per * cprm.nLoopPerEntry[idx], dtype=got.dtype, device=got.device)
+            for n in range(nev):
+                R.data.copy_(f[n].data)
+                cnt = 0
+                for idisp in range(1, cprm.dispStop[idx] + 1):
+                    displace.doVectorDisplacement(hip.DISPLACE_TYPE_COVARIANT, R, idisp)
+                    if idisp >= cprm.dispStart[idx]:
+                        hip.performLoopContraction(mine[per * cnt:per * (cnt + 1)], f[n], R, sg[n])
+                        cnt += 1
+            ref_slots = got[per * cprm.nLoopOffset[idx]:per * (cprm.nLoopOffset[idx] + cprm.nLoopPerEntry[idx])]
+            e = rel_err(mine.cpu().numpy(), ref_slots.cpu().numpy())
+            assert e < tol, ("Displace class nest", idx, e)
     loop.close()
     dist.barrier()
     dist.destroy_process_group()

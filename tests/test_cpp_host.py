@@ -39,6 +39,7 @@ def test_cpp_loop_program_cfg1(hip, tmp_path):
                          capture_output=True, text=True, timeout=300)
     print(out.stdout, out.stderr)
     assert out.returncode == 0 and "LOOP TEST PASSED" in out.stdout and "nLoop = 4" in out.stdout
+    assert "reference loop nest through Displace" in out.stdout
     assert h5.exists() and h5.stat().st_size > 0
     bad = subprocess.run([EXE, "--loop-do-nonlocal", "yes", "--displace-entry-string", "+w:1"], capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "Cannot parse given displacement string" in bad.stderr

@@ -26,6 +26,57 @@ def _setup(hip, X, nev, prec, order, seed, pad=0, gpad=0):
     return ev, Uo, f, U
 
 
+@pytest.mark.parametrize("prec,order", [(8, 2), (4, 4)])
+def test_reference_loop_nest_through_displace_class(hip, prec, order):
+    """The loop nest of Loop_Mugiq::computeCoarseLoop (lib/loop_mugiq.cpp:455-509) written down call for call with the
+    mirrors of the reference's own objects -- Displace::setupDisplacement / doVectorDisplacement (lib/displace.cpp:55-67,
+    206-223) and performLoopContraction (lib/contract_wrappers.cu:88-115) -- must give what the driver gives (both plans)
+    and what the oracle gives."""
+    X, nev = (4, 6, 4, 8), 3
+    ev, Uo, f, U = _setup(hip, X, nev, prec, order, 555)
+    sg = sigmas(nev)
+    entry = "+z:1,2;-x:2;+t:3,1;-y:1,3"
+    prm = hip.MugiqLoopParam(gauge=U).set_displace_entry_string(entry)
+    _, s, a, b = orc.parse_disp_entry_string(entry)
+    cprm = orc.LoopComputeParam(s, a, b)
+    V = int(np.prod(X))
+    cdt = torch.complex128 if prec == 8 else torch.complex64
+    dataPos_d = torch.zeros(16 * V * cprm.nLoop, dtype=cdt, device="cuda")
+    nElemPosLocPerLoop = 16 * V
+    displace = hip.Displace(prm, f[0], prec)
+    fineEvecL, fineEvecR = hip.SpinorField(X, prec, order), hip.SpinorField(X, prec, order)
+    for idx in range(-1, cprm.nDispEntries):
+        if idx != -1:
+            displace.setupDisplacement(cprm.dispString[idx])
+        bufOffset = 0 if idx == -1 else nElemPosLocPerLoop * cprm.nLoopOffset[idx]
+        for n in range(nev):
+            fineEvecL.data.copy_(f[n].data)
+            fineEvecR.data.copy_(fineEvecL.data)
+            if idx == -1:
+                hip.performLoopContraction(dataPos_d, fineEvecL, fineEvecR, sg[n])
+                continue
+            dispCount = 0
+            for idisp in range(1, cprm.dispStop[idx] + 1):
+                displace.doVectorDisplacement(hip.DISPLACE_TYPE_COVARIANT, fineEvecR, idisp)
+                if cprm.dispStart[idx] <= idisp <= cprm.dispStop[idx]:
+                    off = bufOffset + nElemPosLocPerLoop * dispCount
+                    hip.performLoopContraction(dataPos_d[off:off + nElemPosLocPerLoop], fineEvecL, fineEvecR, sg[n])
+                    dispCount += 1
+    ref = orc.compute_loop_position_space(ev, np.float32(sg).astype(np.float64) if prec == 4 else sg, cprm, Uo, X)
+    tol = 1e-12 if prec == 8 else 1e-5
+    got = dataPos_d.cpu().numpy()
+    assert rel_err(got, ref) < tol
+    for calc in (hip.LOOP_CALC_TYPE_BASIC_KERNEL, hip.LOOP_CALC_TYPE_OPT_KERNEL):
+        loop = hip.Loop_Mugiq(hip.MugiqLoopParam(gauge=U, calcType=calc).set_displace_entry_string(entry), f, sg)
+        loop.computeCoarseLoop()
+        assert rel_err(loop.dataPos_d.cpu().numpy(), got) < tol
+        loop.close()
+    with pytest.raises(hip.MugiqHipError):
+        displace.setupDisplacement("+w")
+    with pytest.raises(hip.MugiqHipError):
+        displace.doVectorDisplacement(1, fineEvecR, 1)
+
+
 @pytest.mark.parametrize("prec,order", [(8, 2), (8, 4), (4, 2), (4, 4)])
 @pytest.mark.parametrize("calc", ["basic", "opt"])
 def test_driver_single_process_vs_oracle(hip, prec, order, calc):
