@@ -2,17 +2,20 @@
 //
 // Measured on MI355X (profiles/r01_fused_*): the first-generation kernel streams v_n(x) and v_n(x +- k mu) for every slot
 // k from HBM/fabric -- 1 + nslots "units" of 24*B bytes per site and eigenvector -- and sits at the ~6 TB/s fabric limit
-// with no cache reuse (L2 turns over in ~5 us; the shifted data is requested by other workgroups microseconds apart).
-// But v_n(x + k mu) IS v_n at another site of the same straight line along mu.  Here a workgroup owns 64 such lines
-// ("columns": fixed other coordinates, consecutive coordinate j along mu, parity alternating with j) and TJ consecutive
-// positions on them.  Per eigenvector it stages the TJ + Kmax positions it needs in LDS once ([position][12][64 lanes],
-// one plane per wave, coalesced over the lines), and every (position, slot) pair -- one wave each -- reads both its
-// v_n(x) and its shifted v_n(x +- k mu) from LDS.  Global traffic drops from 1 + nslots to (TJ + Kmax)/TJ units per
-// site and eigenvector (TJ = 4, 3 slots: 4 -> 1.75).  The next eigenvector's global loads are in flight while the
-// current one is consumed (register double buffer, two barriers per eigenvector).
+// with no cache reuse.  But v_n(x + k mu) IS v_n at another site of the same straight line along mu.  Here a workgroup owns
+// 32 such lines ("columns": fixed other coordinates, consecutive coordinate j along mu, parity alternating with j) and TJ
+// consecutive positions on them.  Per eigenvector it stages the TJ + Kmax positions it needs in LDS once (one component
+// plane per wave, 512-byte runs over the lines), and every (position, slot) pair -- one wave each -- reads both its v_n(x)
+// and its shifted v_n(x +- k mu) from LDS.  A workgroup requests (TJ + Kmax)/TJ units per site and eigenvector (TJ = 4,
+// 3 slots: 1.75); with the XCD-contiguous workgroup order the Kmax halo positions are the core positions of the
+// neighbouring tile on the same XCD and come out of its L2, so the HBM traffic is read-once (PMC: 27-28 GB per entry
+// against 45 GB with the plain order, profiles/r02_pmc_extra_traffic.txt).  What bounds the kernel is fp64 issue at the
+// clock the device grants under this mix of FMAs, LDS reads and loads (1.72-1.78 GHz, profiles/r02_kernel_clocks.txt).
+// Staging: global -> LDS directly with three tile buffers (fp64 FLOAT2, <= 8 positions), otherwise through registers with
+// two buffers; one LDS-only barrier per eigenvector either way.
 // Positions beyond the local extent come from the ghost layers (partitioned) or wrap around (periodic), exactly as in
-// the first-generation kernel.  Requirements: DIR >= 1 (along x the line runs inside the coalescing direction; that
-// case keeps the first-generation kernel), X[DIR] % TJ == 0, at most 3 slots per launch.
+// the first-generation kernel.  Requirements: X[DIR] % TJ == 0, at most 3 slots per launch; DIR == 0 is the row tile
+// (whole x-rows per workgroup, see the kernel; rows that do not fill 32 lanes go to csrc/fused_tile16.hip).
 #include "internal.h"
 
 #include <algorithm>
