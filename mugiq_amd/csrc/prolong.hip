@@ -16,6 +16,7 @@
 // written: the ultra-local loop of the MG path costs one pass over V instead of N_ev fine-vector writes + reads.
 #include "internal.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -932,6 +933,274 @@ static int coarse_plan(const MugiqHipTransfer *T, const MugiqHipCoarseField *coa
   return -1;
 }
 
+
+// ---- prolongate-to-fine on the matrix pipe -------------------------------------------------------------------------------
+// out_n(x; s, c) = sum_j V(x; s, c, j) phi_n(X(x); chi(s), j) for all eigenvectors n is, per aggregate X and chirality, the
+// complex GEMM [256 sites x 6 (s, c)] x [n_vec] . [n_vec x N_ev] with phi shared by every site of the aggregate -- the same
+// operand sharing as the congruence above, and the same transposed real form:  D[(n, re | im)][site] = Phi'^T V'^T  on
+// v_mfma_f64_16x16x4_f64, the site staying on the lane (column l & 15).  One workgroup per aggregate, eight waves: a wave owns
+// one chirality and up to kPmPairs blocks of eight eigenvectors, whose fragments of Phi'^T (n_vec / 2 doubles per block) stay
+// in registers for the whole aggregate; a B fragment (Re and Im of one V element = two k-steps) is one ds_read_b128 and
+// feeds every block of the wave.  The rows of Phi'^T are ordered so that a lane ends up with (Re, Im) of eigenvectors kq
+// and kq + 4 of a block at its site: two 16-byte stores per block, (s, c) and site.  V tile of 16 sites x 12 n_vec rows
+// double-buffered in LDS by global_load_lds_dwordx4 exactly as in fine_congruence_mfma_kernel; XCD-contiguous aggregate
+// order; fragments of Phi'^T from an eigenvector-major copy of the coarse eigenvectors (coarse_pack_kernel): whole lines.
+//
+// Measured (32^4, n_vec 24, 200 eigenvectors; profiles/r02_prolong_mfma_probes.txt): 17.8 ms against 28.9 ms for the vector
+// kernel above (which gives every lane its own coarse operands -- consecutive x_cb belong to different aggregates -- and
+// reaches 17 TFLOP/s).  Without its stores the kernel takes 10.4 ms (48 TFLOP/s); the stores are what is left: the 16 sites
+// of an aggregate are eight 32-byte pieces of a fine field, and L2 hands about half of them to memory as 32-byte requests
+// (TCC_EA0_WRREQ against _64B).  Tried and dropped, all slower: non-temporal stores (51 ms); the x-neighbouring aggregates as
+// waves of one workgroup in step, so that the pieces of a line meet in L2 (28.8 ms); alternating the neighbours inside one
+// workgroup tile by tile (51 ms); aggregate pairs per wave with the 64-byte sector completed inside the store instruction
+// by a quad permutation (39.9 ms).  Every wait in the loop is vmcnt(0): loads and stores share that counter and complete out
+// of order with respect to each other, so a counted wait with stores in flight is not safe.
+constexpr int kPmWaves = 8;  // waves per workgroup: even ones take chirality 0, odd ones chirality 1
+constexpr int kPmPairs = 4;  // eight-eigenvector blocks a wave keeps resident (measured: 12-16 blocks per pass beat 24 and 8)
+
+struct ProlongMfmaArgs {
+  const Cplx<double> *V;  // [parity][(3s+c)*NV + j][x_cb]
+  int64_t Vpo;
+  int Vstride;
+  int X[4], Xc[4], bs[4];
+  int volumeCB, volumeCBc, aggVol;
+  const void *const *table;    // device table: nVec coarse bodies, then nVec fine bodies
+  const Cplx<double> *packed;  // [coarse site, even-odd][chi][j][n < nVec8]: see coarse_pack_kernel
+  int64_t Cpo;
+  int Cstride;
+  int Fstride;
+  int64_t Fpo;
+  int nVec, nVec8;             // all eigenvectors of the call (nVec8: rounded up to whole blocks)
+  int blkBegin, blkCount;      // this launch: blocks [blkBegin, blkBegin + blkCount) of eight eigenvectors
+};
+
+// packed[((site * 2 + chi) * NV + j) * nVec8 + n] = phi_n(site; chi, j), site = parity * volumeCBc + x_cb_c, zero for
+// nVec <= n < nVec8.  A fragment load of a wave (16 rows = 8 eigenvectors x re | im, 4 values of j) is then four 128-byte
+// lines; from the fields themselves it would be 32 scattered 16-byte pieces of 32 different lines.
+__global__ __launch_bounds__(256) void coarse_pack_kernel(ProlongMfmaArgs a, int NV) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)2 * a.volumeCBc * 2 * NV * a.nVec8;
+  if (idx >= total) return;
+  const int n = (int)(idx % a.nVec8);
+  const int64_t r = idx / a.nVec8;
+  const int cj = (int)(r % (2 * NV));
+  const int64_t siteEo = r / (2 * NV);
+  const int cpar = (int)(siteEo / a.volumeCBc), xc = (int)(siteEo - (int64_t)cpar * a.volumeCBc);
+  Cplx<double> v{0.0, 0.0};
+  if (n < a.nVec) v = static_cast<const Cplx<double> *>(a.table[n])[(int64_t)cpar * a.Cpo + (int64_t)cj * a.Cstride + xc];
+  const_cast<Cplx<double> *>(a.packed)[idx] = v;
+}
+
+template <int NV> __global__ __launch_bounds__(64 * kPmWaves) void prolong_mfma_kernel(ProlongMfmaArgs a) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  typedef double vec2 __attribute__((ext_vector_type(2)));
+  constexpr int KS = NV / 2;  // k-steps of one (s, c): 2 n_vec / 4
+  constexpr int ROWS = 12 * NV, LDV = kCmS, NT = 64 * kPmWaves, NLD = (ROWS * kCmS) / NT;
+  static_assert((ROWS * kCmS) % NT == 0 && NV % 8 == 0, "tile staging assumes whole wave instructions");
+  extern __shared__ __align__(16) unsigned char smem[];
+  Cplx<double> *Vs0 = reinterpret_cast<Cplx<double> *>(smem);  // two buffers [(s*3 + c)*NV + j][16 sites]
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int kq = lane >> 4, site = lane & 15;
+  const int chi = wave & 1, b0 = wave >> 1;  // my blocks: blkBegin + b0, + 4, + 8, ...
+  int npairs = 0;
+#pragma unroll
+  for (int i = 0; i < kPmPairs; i++)
+    if (b0 + 4 * i < a.blkCount) npairs = i + 1;
+
+  int cc[4], rr = xcd_contiguous_block(blockIdx.x, gridDim.x);
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    cc[d] = rr % a.Xc[d];
+    rr /= a.Xc[d];
+  }
+  const int cpar = (cc[0] + cc[1] + cc[2] + cc[3]) & 1;
+
+  // resident fragments of Phi'^T: lane (row = l & 15, k = kq); row <-> (eigenvector (row & 3) + 4 (row >> 3) of the block,
+  // re | im = (row >> 2) & 1); k-steps 2 m | 2 m + 1 <-> (j = 4 m + kq, V_re | V_im):
+  //   re row:  phi_re V_re - phi_im V_im      im row:  phi_im V_re + phi_re V_im
+  double afrag[kPmPairs][KS];
+  Cplx<double> *fineP[kPmPairs][2];  // bodies of eigenvectors 8 b + kq and 8 b + kq + 4 (what this lane stores), or NULL
+  {
+    const int rowA = lane & 15, riA = (rowA >> 2) & 1;
+    const Cplx<double> *pk = a.packed + (((int64_t)cpar * a.volumeCBc + (lex_index(cc, a.Xc) >> 1)) * 2 + chi) * (int64_t)NV * a.nVec8 +
+                             (int64_t)kq * a.nVec8 + (rowA & 3) + 4 * (rowA >> 3);
+#pragma unroll
+    for (int i = 0; i < kPmPairs; i++) {
+      const int b = a.blkBegin + b0 + (i < npairs ? 4 * i : 0);  // (blocks past the last one shadow a valid one; they are never used)
+#pragma unroll
+      for (int m = 0; m < KS / 2; m++) {
+        const vec2 cv = *as_global(reinterpret_cast<const vec2 *>(pk + (int64_t)(4 * m) * a.nVec8 + 8 * b));
+        afrag[i][2 * m] = riA == 0 ? cv.x : cv.y;
+        afrag[i][2 * m + 1] = riA == 0 ? -cv.y : cv.x;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int ns = 8 * b + kq + 4 * h;
+        fineP[i][h] = ns < a.nVec ? static_cast<Cplx<double> *>(const_cast<void *>(a.table[a.nVec + ns])) : nullptr;
+      }
+    }
+  }
+  // fine site (parity, x_cb) of aggregate member k (lexicographic inside the block)
+  auto member = [&](int k, int &pty, int &x_cb) {
+    int x[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      x[d] = cc[d] * a.bs[d] + k % a.bs[d];
+      k /= a.bs[d];
+    }
+    pty = (x[0] + x[1] + x[2] + x[3]) & 1;
+    x_cb = lex_index(x, a.X) >> 1;
+  };
+  const int stSite = t & 15;
+  auto fetch = [&](int rd, Cplx<double> *buf) {
+    int pty, x_cb;
+    member(rd * kCmS + stSite, pty, x_cb);
+    const Cplx<double> *base = a.V + (int64_t)pty * a.Vpo + x_cb;
+#pragma unroll
+    for (int q = 0; q < NLD; q++) {
+      const int row = (t + NT * q) >> 4;
+      (void)row, (void)base, (void)buf;
+#if defined(__HIP_DEVICE_COMPILE__)  // (a device-only builtin: the host pass of hipcc must not see it)
+      typedef __attribute__((address_space(3))) void lds_void;
+      __builtin_amdgcn_global_load_lds(as_global(reinterpret_cast<const vec2 *>(base + (int64_t)row * a.Vstride)),
+                                       (lds_void *)(buf + (wave * 64 + NT * q)), 16, 0, 0);
+#endif
+    }
+  };
+
+  const int rounds = a.aggVol / kCmS;
+  fetch(0, Vs0);
+  for (int rd = 0; rd < rounds; rd++) {
+    const Cplx<double> *Vs = Vs0 + (rd & 1) * ROWS * LDV;
+    // my share of this round's tile has landed and my stores of the previous round have left (one counter for both, not in
+    // order with respect to each other: nothing short of zero is safe); after the barrier everybody's has, and nobody reads
+    // the other buffer any more
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (rd + 1 < rounds) fetch(rd + 1, Vs0 + ((rd + 1) & 1) * ROWS * LDV);
+    int pty, x_cb;
+    member(rd * kCmS + site, pty, x_cb);
+    const int64_t foff = (int64_t)pty * a.Fpo + x_cb;
+#pragma unroll 1
+    for (int scl = 0; scl < 6; scl++) {
+      const int sc = 6 * chi + scl;  // (s, c) = (2 chi + scl / 3, scl % 3): row block (s*3 + c) * NV of the tile
+      Cplx<double> bf[KS / 2];
+#pragma unroll
+      for (int m = 0; m < KS / 2; m++) bf[m] = Vs[(sc * NV + 4 * m + kq) * LDV + site];
+      const int64_t soff = foff + (int64_t)sc * a.Fstride;
+      // plain stores: the pieces of a line must be able to meet in L2 (non-temporal stores of 32-byte pieces: 3 x slower)
+#define MUGIQ_PM_STORE(i_, acc_)                                                                                        \
+  {                                                                                                                     \
+    if (fineP[i_][0]) *as_global(reinterpret_cast<vec2 *>(fineP[i_][0] + soff)) = vec2{acc_[0], acc_[1]};               \
+    if (fineP[i_][1]) *as_global(reinterpret_cast<vec2 *>(fineP[i_][1] + soff)) = vec2{acc_[2], acc_[3]};               \
+  }
+      // two blocks at a time: their accumulation chains are independent, so the matrix pipe always has a second instruction
+#pragma unroll
+      for (int i = 0; i < kPmPairs; i += 2) {
+        if (i + 1 < npairs) {
+          const int i1 = i + 1 < kPmPairs ? i + 1 : i;
+          d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+          for (int m = 0; m < KS / 2; m++) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[i][2 * m], bf[m].re, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[i1][2 * m], bf[m].re, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[i][2 * m + 1], bf[m].im, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[i1][2 * m + 1], bf[m].im, acc1, 0, 0, 0);
+          }
+          MUGIQ_PM_STORE(i, acc0)
+          MUGIQ_PM_STORE(i1, acc1)
+        } else if (i < npairs) {
+          d4 acc0 = {0, 0, 0, 0};
+#pragma unroll
+          for (int m = 0; m < KS / 2; m++) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[i][2 * m], bf[m].re, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[i][2 * m + 1], bf[m].im, acc0, 0, 0, 0);
+          }
+          MUGIQ_PM_STORE(i, acc0)
+        }
+      }
+#undef MUGIQ_PM_STORE
+    }
+  }
+}
+
+// The fine fields must be FLOAT2 fp64, n_vec 8 | 16 | 24 (two V tiles fit the LDS), aggregates of a multiple of 16 sites.
+// Returns -1 if the shape is not covered (the caller uses the vector kernel); MUGIQ_HIP_PROLONG_MFMA=0 switches it off.
+static int prolong_mfma_plan(const MugiqHipTransfer *T, const MugiqHipCoarseField *coarse, const MugiqHipSpinorField *fine, int nVec,
+                             hipStream_t stream) {
+  const int NV = T->nVec;
+  if (!(NV == 8 || NV == 16 || NV == 24)) return -1;
+  if (const char *e = getenv("MUGIQ_HIP_PROLONG_MFMA"))
+    if (atoi(e) == 0) return -1;
+  long long vol = 1, volc = 1, aggVol = 1;
+  for (int d = 0; d < 4; d++) {
+    vol *= T->X[d];
+    volc *= T->X[d] / T->geoBlockSize[d];
+    aggVol *= T->geoBlockSize[d];
+  }
+  if (aggVol % kCmS != 0) return -1;
+  ProlongMfmaArgs a;
+  a.V = static_cast<const Cplx<double> *>(T->V);
+  a.Vpo = T->parity_offset;
+  a.Vstride = T->stride;
+  for (int d = 0; d < 4; d++) {
+    a.X[d] = T->X[d];
+    a.bs[d] = T->geoBlockSize[d];
+    a.Xc[d] = T->X[d] / T->geoBlockSize[d];
+  }
+  a.volumeCB = (int)(vol / 2);
+  a.volumeCBc = (int)(volc / 2);
+  a.aggVol = (int)aggVol;
+  a.Cpo = coarse[0].parity_offset;
+  a.Cstride = coarse[0].stride;
+  a.Fstride = fine[0].stride;
+  a.Fpo = fine[0].parity_offset;
+  a.nVec = nVec;
+  a.nVec8 = (nVec + 7) / 8 * 8;
+  std::vector<const void *> host(2 * (size_t)nVec);
+  for (int n = 0; n < nVec; n++) {
+    host[n] = coarse[n].data;
+    host[nVec + n] = fine[n].data;
+  }
+  void *dev = nullptr;
+  int st = upload_table(&dev, host.data(), sizeof(void *) * host.size(), stream);
+  if (st) return st;
+  a.table = reinterpret_cast<const void *const *>(dev);
+  void *ws = nullptr;
+  const size_t packBytes = sizeof(Cplx<double>) * (size_t)volc * 2 * NV * (size_t)a.nVec8;
+  if ((st = stream_workspace(&ws, packBytes, stream))) return st;
+  a.packed = static_cast<const Cplx<double> *>(ws);
+  const int64_t total = (int64_t)volc * 2 * NV * a.nVec8;
+  hipLaunchKernelGGL(coarse_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, NV);
+  MUGIQ_CHECK_HIP(hipGetLastError());
+  // passes: a workgroup keeps 4 * kPmPairs blocks of eight eigenvectors per chirality resident; more eigenvectors than that
+  // are split evenly (V is staged once per pass: 12 n_vec 16 B per site against 192 B per site and eigenvector written)
+  int cap = 4 * kPmPairs;
+  if (const char *e = getenv("MUGIQ_HIP_PROLONG_PASS_BLOCKS")) {  // experiments: blocks of eight eigenvectors per pass (<= 4 kPmPairs)
+    const int c = atoi(e);
+    if (c >= 1 && c <= 4 * kPmPairs) cap = c;
+  }
+  const int blocks = a.nVec8 / 8;
+  const int passes = (blocks + cap - 1) / cap;
+  const int blocksPerPass = (blocks + passes - 1) / passes;
+  const size_t shmem = 2 * sizeof(Cplx<double>) * (size_t)12 * NV * kCmS;
+  for (int b = 0; b < blocks; b += blocksPerPass) {
+    a.blkBegin = b;
+    a.blkCount = std::min(blocksPerPass, blocks - b);
+#define MUGIQ_PM_LAUNCH(N_)                                                                                             \
+  {                                                                                                                     \
+    auto kern = prolong_mfma_kernel<N_>;                                                                                \
+    if (shmem > 64 * 1024)                                                                                              \
+      MUGIQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)volc), dim3(64 * kPmWaves), shmem, stream, a);                              \
+  }
+    if (NV == 8) MUGIQ_PM_LAUNCH(8) else if (NV == 16) MUGIQ_PM_LAUNCH(16) else MUGIQ_PM_LAUNCH(24)
+#undef MUGIQ_PM_LAUNCH
+    MUGIQ_CHECK_HIP(hipGetLastError());
+  }
+  return MUGIQ_HIP_SUCCESS;
+}
+
 }  // namespace mugiq
 
 using namespace mugiq;
@@ -954,7 +1223,11 @@ int mugiq_hip_prolongate_batched(const MugiqHipSpinorField *fine_h, const MugiqH
   for (int d = 0; d < 4; d++) MUGIQ_REQUIRE(fine_h[0].X[d] == transfer->X[d], "%s: fine X[%d] mismatch", who, d);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int p = transfer->precision, o = fine_h[0].field_order;
-  if (p == 8 && o == 2) return launch_prolong<double, double, 2, true, false>(transfer, coarse_h, fine_h, nullptr, nullptr, nVec, s);
+  if (p == 8 && o == 2) {
+    const int rc = prolong_mfma_plan(transfer, coarse_h, fine_h, nVec, s);  // the matrix-pipe form where the shape allows
+    if (rc >= 0) return rc;
+    return launch_prolong<double, double, 2, true, false>(transfer, coarse_h, fine_h, nullptr, nullptr, nVec, s);
+  }
   if (p == 8 && o == 4) return launch_prolong<double, double, 4, true, false>(transfer, coarse_h, fine_h, nullptr, nullptr, nVec, s);
   if (p == 4 && o == 2) return launch_prolong<float, float, 2, true, false>(transfer, coarse_h, fine_h, nullptr, nullptr, nVec, s);
   return launch_prolong<float, float, 4, true, false>(transfer, coarse_h, fine_h, nullptr, nullptr, nVec, s);
