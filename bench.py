@@ -367,6 +367,25 @@ def extra_mg(hip, device):
             "roofline": roof("fp64_vector", "coarse_outer_kernel + fine_congruence_kernel", best, byts, flops,
                              note="flops of the coarse-grid plan actually executed (outer product on the coarse grid + V C V^dag per fine "
                                   "site), not of the per-eigenvector prolongation it replaces (8*12*n_vec*V*N_ev = %.0f GFLOP)" % (8.0 * 12 * nvec * V * nev / 1e9))}
+    # prolongateEvecs: coarse -> fine for all eigenvectors, the first step of every DISPLACED MG loop (lib/loop_mugiq.cpp:482)
+    try:
+        big = torch.empty(nev * 24 * (V // 2), dtype=torch.complex128, device=device)
+        ff = [hip.SpinorField(X, 8, 2, data=big[n * 24 * (V // 2):(n + 1) * 24 * (V // 2)]) for n in range(nev)]
+        pms = []
+        for r in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            hip.prolongateEvecs(ff, cf, T)
+            e1.record()
+            torch.cuda.synchronize()
+            pms.append(e0.elapsed_time(e1))
+        pbest = min(pms[1:])
+        res["prolongate_to_fine"] = roof("fp64_vector", "prolong_mfma_kernel<24> x passes + coarse_pack_kernel (prolongateEvecs, all %d eigenvectors)" % nev,
+                                         pbest, V * nev * 192 + V * 12 * nvec * 16, 8.0 * 12 * nvec * V * nev,
+                                         note="algorithmic bytes = the fine eigenvectors written once + V read once; fp64 MFMA shares the vector peak")
+        del ff, big
+    except Exception as e:                                            # (never take the headline down with an extra)
+        res["prolongate_to_fine"] = {"error": repr(e)}
     a1, a2 = attach_traffic({}, ["coarse_outer_kernel"]), attach_traffic({}, ["fine_congruence"])
     if a1.get("traffic") and a2.get("traffic"):
         res["roofline"]["traffic"] = a1["traffic"] + a2["traffic"]
