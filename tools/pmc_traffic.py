@@ -4,7 +4,8 @@ HBM bytes per launch, corrected as /opt/skills/guides/MI355X_MICROARCH.md (secti
 FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE reports exactly 1/2 of the bytes of a wide (16 B/lane)
 coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel-substring> <workload> <out.json>
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel-substring> <workload> <out.json> [grid-size]
+(grid-size: only launches of that many work-items, when the run holds the kernel at several sizes)
 """
 import csv
 import hashlib
@@ -22,9 +23,12 @@ def source_fingerprint():
     return h.hexdigest()[:12]
 
 
+GRID = sys.argv[6] if len(sys.argv) > 6 else None
+
+
 def mean_counter(path, kernel, name):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-            if kernel in r["Kernel_Name"] and r["Counter_Name"] == name]
+            if kernel in r["Kernel_Name"] and r["Counter_Name"] == name and (GRID is None or r["Grid_Size"] == GRID)]
     return sum(vals) / len(vals), len(vals)
 
 
