@@ -9,7 +9,7 @@ mkdir -p $O
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; tail -2 $O/pytest.log
 timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o bench -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err || exit 1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o bench -- python3 $R/bench.py --no-extra --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O -o pmc_$c -- python3 $R/bench.py --steps 4 --warmup 1 --extra displaced,mg --no-cpu-baseline > $O/pmc_$c.json 2> $O/pmc_$c.err || exit 1
 done
