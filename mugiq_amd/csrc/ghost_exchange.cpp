@@ -43,6 +43,8 @@ extern "C" int mugiq_hip_exchange_ghost_vec(const MugiqHipSpinorField *v, const 
 
 // ---- what Displace asks of QUDA's ColorSpinorField for its auxiliary vector (lib/displace.cpp:26-30,40-60): Create with
 // QUDA_ZERO_FIELD_CREATE, operator=, blas::zero -- for hosts that do not manage device memory themselves.
+extern "C" int mugiq_hip_free_spinor(MugiqHipSpinorField *f);
+
 extern "C" int mugiq_hip_alloc_spinor_like(MugiqHipSpinorField *out, const MugiqHipSpinorField *like, int precision, const int ghostDims[4]) {
   using namespace mugiq;
   const char *who = "mugiq_hip_alloc_spinor_like";
@@ -54,14 +56,26 @@ extern "C" int mugiq_hip_alloc_spinor_like(MugiqHipSpinorField *out, const Mugiq
   for (int d = 0; d < 4; d++) out->ghost[d][0] = out->ghost[d][1] = nullptr;
   const size_t cb = 2 * (size_t)out->precision;
   const size_t bytes = (size_t)2 * (size_t)out->parity_offset * cb;
-  MUGIQ_CHECK_HIP(hipMalloc(&out->data, bytes));
-  MUGIQ_CHECK_HIP(hipMemset(out->data, 0, bytes));
+  // (on any failure everything allocated so far is released again: the caller gets either a complete field or nothing)
+  auto fail = [&](hipError_t e, const char *what) {
+    (void)mugiq_hip_free_spinor(out);
+    return set_error(MUGIQ_HIP_ERROR_HIP, "%s: %s failed: %s", who, what, hipGetErrorString(e));
+  };
+  hipError_t e = hipMalloc(&out->data, bytes);
+  if (e != hipSuccess) {
+    out->data = nullptr;
+    return fail(e, "hipMalloc");
+  }
+  if ((e = hipMemset(out->data, 0, bytes)) != hipSuccess) return fail(e, "hipMemset");
   for (int d = 0; d < 4 && ghostDims; d++) {
     if (!ghostDims[d]) continue;
     const size_t gb = (size_t)24 * (size_t)(out->volumeCB / out->X[d]) * cb;
     for (int b = 0; b < 2; b++) {
-      MUGIQ_CHECK_HIP(hipMalloc(&out->ghost[d][b], gb));
-      MUGIQ_CHECK_HIP(hipMemset(out->ghost[d][b], 0, gb));
+      if ((e = hipMalloc(&out->ghost[d][b], gb)) != hipSuccess) {
+        out->ghost[d][b] = nullptr;
+        return fail(e, "hipMalloc");
+      }
+      if ((e = hipMemset(out->ghost[d][b], 0, gb)) != hipSuccess) return fail(e, "hipMemset");
     }
   }
   return MUGIQ_HIP_SUCCESS;
