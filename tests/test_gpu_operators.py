@@ -871,3 +871,41 @@ def test_full_size_cfg4_mg_plans_agree(hip, monkeypatch, record_max):
     e = torch.max(torch.abs(loop.dataPos_d - out["coarse"])).item() / scale
     assert e < 1e-13
     loop.close()
+
+
+def test_spinor_alloc_copy_zero_helpers(hip):
+    """mugiq_hip_alloc_spinor_like / _copy_spinor / _zero_spinor / _free_spinor: what Displace asks of QUDA's ColorSpinorField for
+    its auxiliary vector (lib/displace.cpp:26-30,42,59) -- a zeroed twin with the same geometry, a value copy, blas::zero."""
+    import ctypes
+    from mugiq_amd import _lib
+    lib = _lib.load()
+    X = (4, 6, 4, 8)
+    rng = np.random.default_rng(5)
+    v = orc.lex_to_eo(random_spinor_lex(rng, X), X)
+    src = hip.SpinorField(X, 8, 2, pad=6).set_logical(v)
+    d_src = src.desc()
+    twin = _lib.SpinorDesc()
+    ghost = (ctypes.c_int * 4)(0, 0, 1, 0)
+    assert lib.mugiq_hip_alloc_spinor_like(ctypes.byref(twin), ctypes.byref(d_src), 0, ghost) == 0
+    assert twin.data and twin.stride == d_src.stride and twin.parity_offset == d_src.parity_offset and twin.precision == 8
+    assert twin.ghost[2][0] and twin.ghost[2][1] and not twin.ghost[3][0]
+    n = 2 * src.parity_offset
+    back = torch.empty(n, dtype=torch.complex128, device="cuda")
+    def fetch(desc):
+        assert torch.cuda.current_stream().cuda_stream is not None
+        import ctypes as C
+        hipMemcpy = C.CDLL("libamdhip64.so").hipMemcpy
+        assert hipMemcpy(C.c_void_p(back.data_ptr()), C.c_void_p(desc.data), C.c_size_t(n * 16), C.c_int(3)) == 0   # device to device
+        torch.cuda.synchronize()
+        return back.cpu().numpy().copy()
+    assert not fetch(twin).any()                                                     # QUDA_ZERO_FIELD_CREATE
+    assert lib.mugiq_hip_copy_spinor(ctypes.byref(twin), ctypes.byref(d_src), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(fetch(twin), src.data.cpu().numpy())
+    assert lib.mugiq_hip_zero_spinor(ctypes.byref(twin), None) == 0
+    torch.cuda.synchronize()
+    assert not fetch(twin).any()
+    other = hip.SpinorField(X, 8, 4)                                                  # different order: the copy must refuse
+    d_o = other.desc()
+    assert lib.mugiq_hip_copy_spinor(ctypes.byref(twin), ctypes.byref(d_o), None) != 0
+    assert lib.mugiq_hip_free_spinor(ctypes.byref(twin)) == 0 and not twin.data and not twin.ghost[2][0]
