@@ -3,6 +3,8 @@
 //   mode 0: a wave instruction writes 64 consecutive checkerboard sites of one plane of one field (1 KB run)
 //   mode 1: ... 16 consecutive sites of 4 different fields (256-byte runs; the vector prolongation kernel's pattern)
 //   mode 3 / 4: like mode 2 but 64-byte / 128-byte pieces (2 / 4 x-neighbouring aggregates side by side in the instruction)
+//   mode 5: the 32-byte pieces of mode 2, but the wave that writes aggregate ax's pieces writes those of its three x-neighbours in the next
+//           three instructions (the lines are completed by consecutive instructions of one wave instead of inside one instruction)
 //   mode 2: the matrix-pipe kernel's pattern: 16 lanes = the (x 0..3) x (y 0..3) sites of one 4^4 aggregate at fixed (z, t):
 //           eight 32-byte pieces (two x_cb of one parity) in eight different lines, 4 fields per instruction
 // build: hipcc --offload-arch=gfx950 -O3 -o store_pattern_probe store_pattern_probe.hip ; run: ./store_pattern_probe
@@ -40,7 +42,13 @@ template <int MODE> __global__ __launch_bounds__(256) void store_kernel(vec2 *ba
     const int kq = lane >> 4, s = lane & 15;
     const int x = 4 * ax + (s & 3), y = 4 * ay + (s >> 2), z = 4 * az + (r & 3), t = 4 * at + (r >> 2);
     const size_t pty = (x + y + z + t) & 1, xcb = ((size_t)x + L * ((size_t)y + L * ((size_t)z + L * (size_t)t))) >> 1;
-    if (MODE == 2) {
+    if (MODE == 5) {
+      if (ax % 4) return;
+      for (int f = 4 * wave + kq; f < nf; f += 16)
+        for (int p = 0; p < NPL; p++)
+#pragma unroll
+          for (int gg = 0; gg < 4; gg++) base[f * fieldStride + pty * NPL * VCB + (size_t)p * VCB + xcb + 2 * gg] = val;
+    } else if (MODE == 2) {
       for (int f = 4 * wave + kq; f < nf; f += 16)
         for (int p = 0; p < NPL; p++) base[f * fieldStride + pty * NPL * VCB + (size_t)p * VCB + xcb] = val;
     } else {
@@ -68,9 +76,10 @@ int main() {
   hipEvent_t e0, e1;
   CHK(hipEventCreate(&e0));
   CHK(hipEventCreate(&e1));
-  const char *names[5] = {"1 KB runs (64 lanes contiguous, one field)", "256-byte runs, 4 fields per instruction", "32-byte pieces of an aggregate, 4 fields per instruction",
-                          "64-byte pieces (2 aggregates side by side)", "128-byte pieces (4 aggregates side by side)"};
-  for (int mode = 0; mode < 5; mode++) {
+  const char *names[6] = {"1 KB runs (64 lanes contiguous, one field)", "256-byte runs, 4 fields per instruction", "32-byte pieces of an aggregate, 4 fields per instruction",
+                          "64-byte pieces (2 aggregates side by side)", "128-byte pieces (4 aggregates side by side)",
+                          "32-byte pieces, the other three quarters of each line in the next three instructions of the same wave"};
+  for (int mode = 0; mode < 6; mode++) {
     float best = 1e30f;
     for (int rep = 0; rep < 4; rep++) {
       CHK(hipEventRecord(e0));
@@ -78,7 +87,8 @@ int main() {
       else if (mode == 1) hipLaunchKernelGGL(store_kernel<1>, dim3(2 * VCB / 16), dim3(256), 0, 0, d, NF);
       else if (mode == 2) hipLaunchKernelGGL(store_kernel<2>, dim3(8 * 8 * 8 * 8 * 16), dim3(256), 0, 0, d, NF);
       else if (mode == 3) hipLaunchKernelGGL(store_kernel<3>, dim3(8 * 8 * 8 * 8 * 16), dim3(256), 0, 0, d, NF);
-      else hipLaunchKernelGGL(store_kernel<4>, dim3(8 * 8 * 8 * 8 * 16), dim3(256), 0, 0, d, NF);
+      else if (mode == 4) hipLaunchKernelGGL(store_kernel<4>, dim3(8 * 8 * 8 * 8 * 16), dim3(256), 0, 0, d, NF);
+      else hipLaunchKernelGGL(store_kernel<5>, dim3(8 * 8 * 8 * 8 * 16), dim3(256), 0, 0, d, NF);
       CHK(hipEventRecord(e1));
       CHK(hipEventSynchronize(e1));
       float ms;
