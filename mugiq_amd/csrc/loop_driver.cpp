@@ -72,7 +72,7 @@ struct MugiqHipLoop_s {
   long long nElemMomTot = 0, nElemMomLoc = 0, nElemPosLoc = 0, nElemPhMat = 0;
   void *dataPos_d = nullptr, *dataPosMP_d = nullptr, *dataMom_d = nullptr, *phaseMatrix_d = nullptr;
   void *dataPos = nullptr, *dataMom_h = nullptr, *dataMom = nullptr, *dataMom_bcast = nullptr;
-  bool dataPosCopied = false, momProjDone = false, computed = false;
+  bool dataPosCopied = false, dataPosPinned = false, momProjDone = false, computed = false;
   // ---- MG coarse path (eigsolve->computeCoarse): coarse eigenvectors + one Transfer level (lib/loop_mugiq.cpp:277-319,482)
   bool coarseMode = false;
   std::vector<MugiqHipCoarseField> coarseVecs;
@@ -1132,7 +1132,13 @@ const void *mugiq_hip_loop_data_pos_d(const MugiqHipLoop *lp) { return lp ? lp->
 const void *mugiq_hip_loop_data_pos_h(MugiqHipLoop *lp) {
   if (!lp) return nullptr;
   const size_t bytes = (size_t)lp->nElemPosLoc * lp->loopBytes();
-  if (!lp->dataPos) lp->dataPos = calloc((size_t)lp->nElemPosLoc, lp->loopBytes());  // lib/loop_mugiq.cpp:116
+  if (!lp->dataPos) {  // lib/loop_mugiq.cpp:116; page-locked so that the copy runs at the link rate (pageable memory: a fraction of it)
+    if (hipHostMalloc(&lp->dataPos, bytes, hipHostMallocDefault) == hipSuccess) lp->dataPosPinned = true;
+    else {
+      (void)hipGetLastError();
+      lp->dataPos = calloc((size_t)lp->nElemPosLoc, lp->loopBytes());
+    }
+  }
   if (!lp->dataPos) return nullptr;
   if (!lp->dataPosCopied) {
     if (hipMemcpy(lp->dataPos, lp->dataPos_d, bytes, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;  // :512
@@ -1196,7 +1202,8 @@ int mugiq_hip_loop_destroy(MugiqHipLoop *lp) {  // freeDataMemory, lib/loop_mugi
   if (lp->dataMom_bcast != lp->dataMom_h) free(lp->dataMom_bcast);
   if (lp->dataMom_h) (void)hipHostFree(lp->dataMom_h);
   if (lp->dataMom != lp->dataMom_h) free(lp->dataMom);
-  free(lp->dataPos);
+  if (lp->dataPosPinned) (void)hipHostFree(lp->dataPos);
+  else free(lp->dataPos);
   if (lp->fineStore) (void)hipFree(lp->fineStore);
   for (void *q : lp->levelStore)
     if (q) (void)hipFree(q);
