@@ -293,9 +293,12 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
                                         ms_i + ms_b, ent_bytes, ent_flops)
             out["roofline"][tag].update({"interior_ms": ms_i, "boundary_ms": ms_b, "halo_wait_ms": phase_sum(ph, "halo_wait", i)})
     ms_u = phase_sum(ph, "ultra_local")
-    out["roofline"]["ultra_local"] = roof("hbm", "loop_contract_kernel", ms_u, V * (nev * 24 * B + 32 * B))
-    if pmc_workload:
-        attach_traffic(out["roofline"]["ultra_local"], ["loop_contract_kernel"], V)
+    if ms_u > 0:
+        out["roofline"]["ultra_local"] = roof("hbm", "loop_contract_kernel", ms_u, V * (nev * 24 * B + 32 * B))
+        if pmc_workload:
+            attach_traffic(out["roofline"]["ultra_local"], ["loop_contract_kernel"], V)
+    else:
+        out["ultra_local"] = "carried by a displaced entry as a fourth slot of the tiled kernel (no pass of its own)"
     ms_r = phase_sum(ph, "entry_reflected")
     nref = sum(3 for d in best["derived"] if d >= 0)
     if nref:

@@ -233,6 +233,18 @@ int mugiq_hip_displaced_loop_contraction_fused_region(void *loopData_d, int loop
                                                       const void *const *pathLinkFields_h, const int *kValues_h, int nK,
                                                       int dispDir, int dispSign, const int commDim[4],
                                                       const void *ghostLayers_d, int layers, int region, void *stream);
+/* The same, and in the same pass over the eigenvectors the ULTRA-LOCAL loop (displacement 0: the loop of lib/loop_mugiq.cpp:499-503,
+ * sum_n (1/sigma_n) v_n^dag G v_n) into ultraLocalSlot_d (16*V complex, same region / overwrite semantics as the displaced slots):
+ * it rides along as one more slot (k = 0, W = 1) of the tiled kernel when that has room -- a free slot of its 12-wave forms, or
+ * the fourth slot of the 16-wave form (fp64 FLOAT2 column tiles with three lengths) -- which saves the separate pass over all
+ * eigenvectors.  *carried = 1 if the slot was produced, 0 if not (then nothing was written to it and the caller computes it
+ * with mugiq_hip_perform_loop_contraction_batched).  ultraLocalSlot_d = NULL: plain _region call. */
+int mugiq_hip_displaced_loop_contraction_fused_carry(void *loopData_d, int loopPrecision,
+                                                     const MugiqHipSpinorField *eVecs_h, const double *sigma_h, int nVec,
+                                                     const void *const *pathLinkFields_h, const int *kValues_h, int nK,
+                                                     int dispDir, int dispSign, const int commDim[4],
+                                                     const void *ghostLayers_d, int layers, int region,
+                                                     void *ultraLocalSlot_d, int *carried, void *stream);
 
 /* ---- a8  Fourier phase matrix -------------------------------------------------------------------------- */
 /* createPhaseMatrixGPU<Float>(phaseMatrix_d, momMatrix_h, locV3, Nmom, FTSign, localL, totalL)

@@ -79,6 +79,10 @@ SIGNATURES = {
                                                                          ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), _I4,
                                                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, _I4, _VP,
                                                                          ctypes.c_int, ctypes.c_int, _VP]),
+    "mugiq_hip_displaced_loop_contraction_fused_carry": (ctypes.c_int, [_VP, ctypes.c_int, _SP, ctypes.POINTER(ctypes.c_double),
+                                                                        ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), _I4,
+                                                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, _I4, _VP,
+                                                                        ctypes.c_int, ctypes.c_int, _VP, _I4, _VP]),
     "mugiq_hip_perform_covariant_displacement_vector": (ctypes.c_int, [_SP, _SP, _GP, ctypes.c_int, ctypes.c_int,
                                                                        _I4, _VP]),
     "mugiq_hip_pack_face": (ctypes.c_int, [_VP, _SP, ctypes.c_int, ctypes.c_int, _VP]),

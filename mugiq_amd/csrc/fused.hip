@@ -267,12 +267,14 @@ int tile16_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigm
 bool tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int precision, int partitioned);
 template <typename F, typename A, int ORDER>
 int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d, const int *kvals,
-               int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, int region, hipStream_t stream);
+               int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, int region, hipStream_t stream,
+               void *ultra_d, int *carried);
 
 template <typename F, typename A, int ORDER>
 static int fused_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d,
                        const int *kvals, int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers,
-                       int region, hipStream_t stream) {
+                       int region, hipStream_t stream, void *ultra_d, int *carried) {
+  if (carried) *carried = 0;
   {
     int kmax = 0;
     for (int i = 0; i < nK; i++) kmax = kvals[i] > kmax ? kvals[i] : kmax;
@@ -280,7 +282,7 @@ static int fused_entry(void *loop_d, const MugiqHipSpinorField *ev, const double
     if (tile16_applicable(ev[0], dir, kmax, ev[0].precision, partitioned, gen2))
       return tile16_entry<F, A, ORDER>(loop_d, ev, sigma, nVec, E_d, kvals, nK, dir, sign, partitioned, ghost_d, layers, region, stream);
     if (gen2)
-      return tile_entry<F, A, ORDER>(loop_d, ev, sigma, nVec, E_d, kvals, nK, dir, sign, partitioned, ghost_d, layers, region, stream);
+      return tile_entry<F, A, ORDER>(loop_d, ev, sigma, nVec, E_d, kvals, nK, dir, sign, partitioned, ghost_d, layers, region, stream, ultra_d, carried);
   }
   // the streaming kernel has no interior / boundary split: when the dimension is partitioned it counts as boundary
   const int overwrite = (region & MUGIQ_HIP_REGION_OVERWRITE) ? 1 : 0;
@@ -376,11 +378,12 @@ int mugiq_hip_pack_face_layers(void *faces_d, const MugiqHipSpinorField *eVecs_h
   return pack_layers<float, 4>(faces_d, eVecs_h, nVec, dim, high, layers, s);
 }
 
-int mugiq_hip_displaced_loop_contraction_fused_region(void *loopData_d, int loopPrecision, const MugiqHipSpinorField *eVecs_h,
-                                                      const double *sigma_h, int nVec, const void *const *pathLinkFields_h,
-                                                      const int *kValues_h, int nK, int dispDir, int dispSign,
-                                                      const int commDim[4], const void *ghostLayers_d, int layers, int region,
-                                                      void *stream) {
+int mugiq_hip_displaced_loop_contraction_fused_carry(void *loopData_d, int loopPrecision, const MugiqHipSpinorField *eVecs_h,
+                                                     const double *sigma_h, int nVec, const void *const *pathLinkFields_h,
+                                                     const int *kValues_h, int nK, int dispDir, int dispSign,
+                                                     const int commDim[4], const void *ghostLayers_d, int layers, int region,
+                                                     void *ultraLocalSlot_d, int *carried, void *stream) {
+  if (carried) *carried = 0;
   const char *who = "mugiq_hip_displaced_loop_contraction_fused";
   MUGIQ_REQUIRE((region & 0xff) == MUGIQ_HIP_REGION_ALL || (region & 0xff) == MUGIQ_HIP_REGION_INTERIOR || (region & 0xff) == MUGIQ_HIP_REGION_BOUNDARY,
                 "%s: invalid region %d", who, region);
@@ -414,7 +417,7 @@ int mugiq_hip_displaced_loop_contraction_fused_region(void *loopData_d, int loop
                 "%s: loop precision %d with field precision %d is not supported", who, loopPrecision, p);
 #define MUGIQ_FUSED_GO(F, A, O)                                                                                                 \
   return fused_entry<F, A, O>(loopData_d, eVecs_h, sigma_h, nVec, pathLinkFields_h, kValues_h, nK, dispDir, dispSign, part,   \
-                              ghostLayers_d, layers, region, s)
+                              ghostLayers_d, layers, region, s, ultraLocalSlot_d, carried)
   if (p == 8 && o == 2) MUGIQ_FUSED_GO(double, double, 2);
   if (p == 8 && o == 4) MUGIQ_FUSED_GO(double, double, 4);
   if (loopPrecision == 8 && o == 2) MUGIQ_FUSED_GO(float, double, 2);
@@ -422,6 +425,16 @@ int mugiq_hip_displaced_loop_contraction_fused_region(void *loopData_d, int loop
   if (o == 2) MUGIQ_FUSED_GO(float, float, 2);
   MUGIQ_FUSED_GO(float, float, 4);
 #undef MUGIQ_FUSED_GO
+}
+
+int mugiq_hip_displaced_loop_contraction_fused_region(void *loopData_d, int loopPrecision, const MugiqHipSpinorField *eVecs_h,
+                                                      const double *sigma_h, int nVec, const void *const *pathLinkFields_h,
+                                                      const int *kValues_h, int nK, int dispDir, int dispSign,
+                                                      const int commDim[4], const void *ghostLayers_d, int layers, int region,
+                                                      void *stream) {
+  return mugiq_hip_displaced_loop_contraction_fused_carry(loopData_d, loopPrecision, eVecs_h, sigma_h, nVec, pathLinkFields_h, kValues_h,
+                                                          nK, dispDir, dispSign, commDim, ghostLayers_d, layers, region, nullptr, nullptr,
+                                                          stream);
 }
 
 int mugiq_hip_displaced_loop_contraction_fused_mixed(void *loopData_d, int loopPrecision, const MugiqHipSpinorField *eVecs_h,

@@ -26,13 +26,13 @@
 namespace mugiq {
 
 constexpr int kTileTJ = 4;        // positions along mu per workgroup
-constexpr int kTileMaxSlots = 3;  // waves = kTileTJ * nslot <= 12
+constexpr int kTileMaxSlots = 3;  // displaced slots per launch: waves = kTileTJ * nslot <= 12
+constexpr int kTileCarry = kTileMaxSlots + 1;  // + the ultra-local loop riding along as a slot with k = 0 (16 waves; GLDS form only)
 constexpr int kTileMaxPos = 16;   // TJ + Kmax upper bound
 constexpr int kTileCols = 32;     // lines per workgroup (each line is held by two lanes: one per spin half)
 
 template <typename F, typename A> struct TileArgs {
-  Cplx<A> *loop;
-  int64_t slot_stride;
+  Cplx<A> *out[kTileCarry];  // where every slot goes
   const void *const *L;
   const A *inv_sigma;
   int nVec;
@@ -40,8 +40,8 @@ template <typename F, typename A> struct TileArgs {
   int volumeCB;
   int stride;
   int64_t parity_offset;
-  const F *E[kTileMaxSlots];
-  int k[kTileMaxSlots];
+  const F *E[kTileCarry];  // path links W_k of every slot; NULL = the identity (k = 0)
+  int k[kTileCarry];
   int nslot;
   int kmax;
   int partitioned;
@@ -75,8 +75,8 @@ template <int ORDER> __device__ inline int64_t comp_offset(int comp, int64_t str
 // (global_load_lds_dwordx4: no stage registers, no ds_write pass) into THREE tile buffers -- one consumed, two in flight.  The
 // transfer wants a lane-linear LDS image, so a buffer is [position pair][12][position & 1][32]: the two lane halves of an
 // instruction (alternate positions, 512 bytes each) land next to each other.
-template <typename F, typename A, int ORDER, int DIR, int SIGN, int PH, bool GLDS>
-__global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileArgs<F, A> a) {
+template <typename F, typename A, int ORDER, int DIR, int SIGN, int PH, bool GLDS, int NW = 12>
+__global__ __launch_bounds__(64 * NW) void tile_displaced_contract_kernel(TileArgs<F, A> a) {
   extern __shared__ __align__(16) unsigned char smem[];
   Cplx<F> *tileBase = reinterpret_cast<Cplx<F> *>(smem);  // 2 (3: GLDS) x [NP][12][32] (buffered over the eigenvectors)
   const size_t tileElems = (size_t)(2 * PH) * 12 * kTileCols;  // padded to 2*PH positions: commits are unconditional
@@ -194,7 +194,8 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
   // -7 % / -9 % per entry), fp64 gets it by prefetching two eigenvectors ahead instead of three (the kernel is bound by
   // vector issue, not by memory latency: -3.6 % column, -2 % row tile; three-deep AND W in registers spills, +35 %).
   Cplx<A> Wr[9];
-  {
+  const bool unitW = a.E[slot] == nullptr;
+  if (!unitW) {
     const Cplx<F> *e = reinterpret_cast<const Cplx<F> *>(a.E[slot]) + (int64_t)pmine * 12 * a.volumeCB + xmine;
 #pragma unroll
     for (int j = 0; j < 3; j++)
@@ -203,6 +204,9 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
         const Cplx<F> t = e[(int64_t)(j * 3 + i) * a.volumeCB];
         Wr[i * 3 + j] = Cplx<A>{(A)t.re, (A)t.im};
       }
+  } else {  // the ultra-local loop carried as a slot: k = 0, W = 1
+#pragma unroll
+    for (int i = 0; i < 9; i++) Wr[i] = Cplx<A>{A(i % 4 == 0 ? 1 : 0), A(0)};
   }
   Cplx<A> acc[8];  // acc[be*2 + a2], al = 2*half + a2
 #pragma unroll
@@ -251,6 +255,13 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
       const Cplx<F> *ts = tile + tileIdx(ppS, half * 6, colS); /* spins 2*half, 2*half + 1 */                          \
       /* t[a2] = s * W * psi[2*half + a2]: each W element and each psi element is read from LDS once */               \
       Cplx<A> t0[3], t1[3];                                                                                            \
+      if (unitW) { /* the carried ultra-local slot: W = 1 (wave-uniform branch) */                                     \
+        _Pragma("unroll") for (int j = 0; j < 3; j++) {                                                                \
+          const Cplx<F> w0 = ts[j * kCompStride], w1 = ts[(3 + j) * kCompStride];                                      \
+          t0[j] = Cplx<A>{(A)w0.re, (A)w0.im};                                                                         \
+          t1[j] = Cplx<A>{(A)w1.re, (A)w1.im};                                                                         \
+        }                                                                                                              \
+      } else {                                                                                                         \
       _Pragma("unroll") for (int i = 0; i < 3; i++) t0[i] = t1[i] = Cplx<A>{A(0), A(0)};                               \
       _Pragma("unroll") for (int j = 0; j < 3; j++) {                                                                  \
         const Cplx<F> w0 = ts[j * kCompStride], w1 = ts[(3 + j) * kCompStride];                                            \
@@ -260,6 +271,7 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
           cmadd(t0[i], w, p0j);                                                                                        \
           cmadd(t1[i], w, p1j);                                                                                        \
         }                                                                                                              \
+      }                                                                                                                \
       }                                                                                                                \
       _Pragma("unroll") for (int i = 0; i < 3; i++) {                                                                  \
         t0[i] = Cplx<A>{s * t0[i].re, s * t0[i].im};                                                                   \
@@ -312,10 +324,12 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
     const Cplx<F> *body_ = bodyExpr_;                                                                                  \
     const Cplx<F> *gh_ = ghostBase + (int64_t)(n_)*a.ghost_vec_stride;                                                 \
     Cplx<F> *dst_ = (buf_) + (size_t)wave * 2 * kTileCols;                                                             \
+    if (NW == 12 || wave < 12) { /* (waves 12-15 of the 16-wave form only compute) */                                  \
     _Pragma("unroll") for (int i = 0; i < PH; i++) {                                                                   \
       const Cplx<F> *ptr_ = (((sghost >> i) & 1u) ? gh_ : body_) + soff[i];                                            \
       __builtin_amdgcn_global_load_lds(as_global(reinterpret_cast<const vec2 *>(ptr_)),                                \
                                        (lds_void *)(dst_ + (size_t)i * 24 * kTileCols), 16, 0, 0);                     \
+    }                                                                                                                  \
     }                                                                                                                  \
   }
     // One step: eigenvector n_ lands in buffer cur_ (own share: counted vmcnt wait; everybody's: the barrier, which also
@@ -408,7 +422,7 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
         full[be * 4 + 2 + a2] = half == 0 ? theirs : mine;
       }
     if (active) {
-      Cplx<A> *out = a.loop + (int64_t)slot * a.slot_stride;
+      Cplx<A> *out = a.out[slot];
       const int siteIdx = xmine + pmine * a.volumeCB;
       if (half == 0) trace_and_store_range<A, 0, 8>(out, full, 2 * a.volumeCB, siteIdx, a.overwrite != 0);
       else trace_and_store_range<A, 8, 16>(out, full, 2 * a.volumeCB, siteIdx, a.overwrite != 0);
@@ -421,12 +435,18 @@ __global__ __launch_bounds__(64 * 12) void tile_displaced_contract_kernel(TileAr
 #undef MUGIQ_TILE_BODY
 #undef MUGIQ_TILE_SIGMA
 
+// global -> LDS staging with three buffers: fp64 FLOAT2 column tiles of at most 8 positions (MUGIQ_HIP_TILE_GLDS=0: off)
+template <typename F, int ORDER> static bool tile_glds(int dir, int kmax) {
+  bool glds = std::is_same<F, double>::value && ORDER == 2 && dir >= 1 && kTileTJ + kmax <= 8;
+  if (const char *e = getenv("MUGIQ_HIP_TILE_GLDS")) glds = glds && atoi(e) != 0;
+  return glds;
+}
+
 template <typename F, typename A, int ORDER> static int launch_tile(TileArgs<F, A> a, int dir, int sign, hipStream_t stream) {
   const int NP = dir >= 1 ? kTileTJ + a.kmax : kTileTJ;
   const int PHsel = NP <= 8 ? 4 : kTileMaxPos / 2;
-  // global -> LDS staging with three buffers: fp64 FLOAT2 column tiles of at most 8 positions (MUGIQ_HIP_TILE_GLDS=0: off)
-  bool glds = std::is_same<F, double>::value && ORDER == 2 && dir >= 1 && NP <= 8;
-  if (const char *e = getenv("MUGIQ_HIP_TILE_GLDS")) glds = glds && atoi(e) != 0;
+  const bool glds = tile_glds<F, ORDER>(dir, a.kmax);
+  const bool carry = a.nslot == kTileCarry;  // (tile_entry adds the fourth slot only where glds holds)
   const size_t tileBytes = (glds ? 3 : 2) * sizeof(Cplx<F>) * (size_t)(2 * PHsel) * 12 * kTileCols;  // padded positions
   const size_t shmem = tileBytes;  // the staging tiles
   a.tileBytes = (int)tileBytes;
@@ -440,10 +460,10 @@ template <typename F, typename A, int ORDER> static int launch_tile(TileArgs<F, 
   a.blockOrder = 2;
   if (const char *e = getenv("MUGIQ_HIP_TILE_ORDER")) a.blockOrder = atoi(e) & 3;
   if (nblocks % 8 != 0) a.blockOrder &= 1;
-  const dim3 grid(nblocks), block(64 * 12);
-#define MUGIQ_TILE_LAUNCH(D, S, P, G)                                                                                 \
+  const dim3 grid(nblocks), block(64 * (carry ? 16 : 12));
+#define MUGIQ_TILE_LAUNCH(D, S, P, G, W)                                                                              \
   {                                                                                                                   \
-    auto kern = tile_displaced_contract_kernel<F, A, ORDER, D, S, P, G>;                                              \
+    auto kern = tile_displaced_contract_kernel<F, A, ORDER, D, S, P, G, W>;                                           \
     if (shmem > 64 * 1024)                                                                                            \
       MUGIQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, a);                                                          \
@@ -452,11 +472,11 @@ template <typename F, typename A, int ORDER> static int launch_tile(TileArgs<F, 
   case (D)*2 + (S):                                                                                                   \
     if constexpr (std::is_same<F, double>::value && ORDER == 2 && (D) >= 1) {                                         \
       if (glds) {                                                                                                     \
-        MUGIQ_TILE_LAUNCH(D, S, 4, true)                                                                              \
+        if (carry) MUGIQ_TILE_LAUNCH(D, S, 4, true, 16) else MUGIQ_TILE_LAUNCH(D, S, 4, true, 12)                     \
         break;                                                                                                        \
       }                                                                                                               \
     }                                                                                                                 \
-    if (NP <= 8) MUGIQ_TILE_LAUNCH(D, S, 4, false) else MUGIQ_TILE_LAUNCH(D, S, kTileMaxPos / 2, false)               \
+    if (NP <= 8) MUGIQ_TILE_LAUNCH(D, S, 4, false, 12) else MUGIQ_TILE_LAUNCH(D, S, kTileMaxPos / 2, false, 12)       \
     break;
   switch (dir * 2 + sign) {
     MUGIQ_TILE_CASE(0, 0) MUGIQ_TILE_CASE(0, 1) MUGIQ_TILE_CASE(1, 0) MUGIQ_TILE_CASE(1, 1)
@@ -489,9 +509,12 @@ bool tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int preci
   return lds <= 160 * 1024;
 }
 
+// ultra_d != NULL: also produce the ultra-local loop (k = 0, W = 1) into ultra_d, as a fourth slot of the 16-wave form; *carried
+// says whether that was possible (fp64 FLOAT2 column tiles staged global -> LDS, at most three displaced slots)
 template <typename F, typename A, int ORDER>
 int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d, const int *kvals,
-               int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, int region, hipStream_t stream) {
+               int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, int region, hipStream_t stream,
+               void *ultra_d, int *carried) {
   const size_t ptr_bytes = sizeof(void *) * (size_t)nVec;
   std::vector<unsigned char> host(ptr_bytes + sizeof(A) * (size_t)nVec);
   const void **hl = reinterpret_cast<const void **>(host.data());
@@ -505,7 +528,8 @@ int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma,
   int st = upload_table(&dev, host.data(), host.size(), stream);
   if (st) return st;
   TileArgs<F, A> a;
-  a.slot_stride = (int64_t)16 * 2 * ev[0].volumeCB;
+  const int64_t slot_stride = (int64_t)16 * 2 * ev[0].volumeCB;
+  if (carried) *carried = 0;
   a.L = reinterpret_cast<const void *const *>(dev);
   a.inv_sigma = reinterpret_cast<const A *>(static_cast<unsigned char *>(dev) + ptr_bytes);
   a.nVec = nVec;
@@ -531,13 +555,21 @@ int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma,
   region &= 0xff;
   for (int k0 = 0; k0 < nK; k0 += kTileMaxSlots) {
     a.nslot = (nK - k0 < kTileMaxSlots) ? nK - k0 : kTileMaxSlots;
-    a.loop = static_cast<Cplx<A> *>(loop_d) + (int64_t)k0 * a.slot_stride;
     a.kmax = 0;
-    for (int s = 0; s < kTileMaxSlots; s++) {
+    for (int s = 0; s < kTileCarry; s++) {
       const int i = k0 + (s < a.nslot ? s : 0);
       a.E[s] = static_cast<const F *>(E_d[i]);
       a.k[s] = kvals[i];
+      a.out[s] = static_cast<Cplx<A> *>(loop_d) + (int64_t)i * slot_stride;
       if (s < a.nslot && kvals[i] > a.kmax) a.kmax = kvals[i];
+    }
+    // room for it: a free slot of the 12-wave forms, or the fourth slot of the 16-wave form (global -> LDS staging only)
+    if (ultra_d && k0 == 0 && nK <= kTileMaxSlots && (nK < kTileMaxSlots || tile_glds<F, ORDER>(dir, a.kmax))) {
+      a.E[a.nslot] = nullptr;
+      a.k[a.nslot] = 0;
+      a.out[a.nslot] = static_cast<Cplx<A> *>(ultra_d);
+      a.nslot++;
+      if (carried) *carried = 1;
     }
     // region 0: everything | 1: tiles whose shifted reads stay inside the local lattice | 2: tiles that read ghost layers
     a.jtBegin = 0;
@@ -564,7 +596,7 @@ int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma,
 
 #define MUGIQ_TILE_INST(F, A, O)                                                                                                 \
   template int tile_entry<F, A, O>(void *, const MugiqHipSpinorField *, const double *, int, const void *const *, const int *, int, \
-                                   int, int, int, const void *, int, int, hipStream_t);
+                                   int, int, int, const void *, int, int, hipStream_t, void *, int *);
 MUGIQ_TILE_INST(double, double, 2)
 MUGIQ_TILE_INST(double, double, 4)
 MUGIQ_TILE_INST(float, float, 2)

@@ -73,6 +73,9 @@ struct MugiqHipLoop_s {
   void *dataPos_d = nullptr, *dataPosMP_d = nullptr, *dataMom_d = nullptr, *phaseMatrix_d = nullptr;
   void *dataPos = nullptr, *dataMom_h = nullptr, *dataMom = nullptr, *dataMom_bcast = nullptr;
   bool dataPosCopied = false, dataPosPinned = false, momProjDone = false, computed = false;
+  // OPT plan: the ultra-local loop rides along with one displaced entry when the tiled kernel has room for it (see
+  // mugiq_hip_displaced_loop_contraction_fused_carry); ultraCarried says whether an entry of this compute has produced it
+  bool carryUltra = false, ultraCarried = false;
   // ---- MG coarse path (eigsolve->computeCoarse): coarse eigenvectors + one Transfer level (lib/loop_mugiq.cpp:277-319,482)
   bool coarseMode = false;
   std::vector<MugiqHipCoarseField> coarseVecs;
@@ -432,10 +435,14 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
     // the slots were not zeroed (see mugiq_hip_loop_compute): the first eigenvector block writes them, later ones add
     const int ow = n0 == 0 ? MUGIQ_HIP_REGION_OVERWRITE : 0;
     if (!part) {
-      if ((st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, &lp->eVecs[n0], &lp->sigma[n0], nv,
-                                                                  links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
-                                                                  nullptr, 0, MUGIQ_HIP_REGION_ALL | ow, lp->stream)))
+      // (one block here: nb = nEv.)  The first such entry also takes the ultra-local loop along, if the kernel has room
+      int carried = 0;
+      void *ultra = (lp->carryUltra && !lp->ultraCarried && nb == lp->nEv) ? lp->dataPos_d : nullptr;
+      if ((st = mugiq_hip_displaced_loop_contraction_fused_carry(slot0, lp->loopPrecision, &lp->eVecs[n0], &lp->sigma[n0], nv,
+                                                                 links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
+                                                                 nullptr, 0, MUGIQ_HIP_REGION_ALL | ow, ultra, &carried, lp->stream)))
         return st;
+      if (carried) lp->ultraCarried = true;
       continue;
     }
     // pack the face layers -> [comm stream] exchange them  ||  [compute stream] interior sites -> boundary sites
@@ -913,6 +920,7 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
   const bool basic = lp->calcType == MUGIQ_HIP_LOOP_CALC_TYPE_BASIC_KERNEL;
   lp->phases.clear();
   lp->eventsUsed = 0;
+  lp->carryUltra = lp->ultraCarried = false;
   const auto tWall0 = std::chrono::steady_clock::now();
   if (lp->coarseMode && lp->levelVecs.size() > 1) {
     // coarsest level -> level 1 through the upper transfer operators (lib/loop_mugiq.cpp:306-311), all eigenvectors per launch
@@ -990,8 +998,18 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
         const bool derived = lp->derivedFrom[id] >= 0, part = lp->commDim[lp->dispDir[id]] != 0;
         if ((pass == 0 && !derived && !part) || (pass == 1 && !derived && part) || (pass == 2 && derived)) order.push_back(id);
       }
+    // the ultra-local loop may ride along with a displaced entry (MUGIQ_HIP_CARRY_ULTRALOCAL=0: never): it then moves to the end
+    // of the order and is skipped if some entry has taken it along
+    lp->carryUltra = lp->nDispEntries > 0 && !lp->coarseMode;
+    if (const char *e = getenv("MUGIQ_HIP_CARRY_ULTRALOCAL")) lp->carryUltra = lp->carryUltra && atoi(e) != 0;
+    lp->ultraCarried = false;
+    if (lp->carryUltra) {
+      order.erase(order.begin());
+      order.push_back(-1);
+    }
   }
   for (int id : order) {
+    if (id == -1 && !basic && lp->carryUltra && lp->ultraCarried) continue;  // produced by a displaced entry's pass
     long long bufOffset;
     size_t bufByteSize;
     if (id != -1) {  // :465-474

@@ -185,13 +185,21 @@ def packLoopLayers(layers_d, slot_d, localL, dim, high, layers):
 
 
 def displacedLoopContractionFused(loopData_d, eVecs, sigmas, pathLinkFields, kValues, dispDir, dispSign,
-                                  commDim=(0, 0, 0, 0), ghostLayers_d=None, layers=0):
-    """loop slot i += sum_n (1/sigma_n) v_n^dag G W_k v_n(x +- k mu), k = kValues[i] (see mugiq_hip.h)."""
+                                  commDim=(0, 0, 0, 0), ghostLayers_d=None, layers=0, ultraLocalSlot_d=None):
+    """loop slot i += sum_n (1/sigma_n) v_n^dag G W_k v_n(x +- k mu), k = kValues[i] (see mugiq_hip.h).
+    ultraLocalSlot_d: also ask for the ultra-local loop (displacement 0) in the same pass; returns whether the kernel carried it."""
     n, nk = len(eVecs), len(kValues)
     d = desc_array(eVecs)
     sg = (ctypes.c_double * n)(*[float(s) for s in sigmas])
     links = (ctypes.c_void_p * nk)(*[f.data.data_ptr() for f in pathLinkFields])
     kv = (ctypes.c_int * nk)(*[int(k) for k in kValues])
+    if ultraLocalSlot_d is not None:
+        carried = ctypes.c_int(0)
+        _lib.check(_lib.load().mugiq_hip_displaced_loop_contraction_fused_carry(
+            loopData_d.data_ptr(), _prec_of(loopData_d), d, sg, n, links, kv, nk, int(dispDir), int(dispSign), _lib.int4(commDim),
+            ghostLayers_d.data_ptr() if ghostLayers_d is not None else None, int(layers), 0, ultraLocalSlot_d.data_ptr(),
+            ctypes.byref(carried), _stream()))
+        return bool(carried.value)
     _lib.check(_lib.load().mugiq_hip_displaced_loop_contraction_fused_mixed(
         loopData_d.data_ptr(), _prec_of(loopData_d), d, sg, n, links, kv, nk, int(dispDir), int(dispSign), _lib.int4(commDim),
         ghostLayers_d.data_ptr() if ghostLayers_d is not None else None, int(layers), _stream()))

@@ -191,6 +191,44 @@ def test_fused_operator_with_ghost_layers(hip, order):
                     assert rel_err(lo, orc.local_block(gl, r, grid)) < 1e-13, (dispstr, r, k, ig)
 
 
+@pytest.mark.parametrize("prec,order,lengths", [(8, 2, [1, 2, 3]), (8, 2, [2]), (8, 4, [1, 2]), (4, 4, [1, 3]), (4, 2, [1, 2, 3]), (8, 4, [1, 2, 3])])
+@pytest.mark.parametrize("dispstr", ["+y", "-t", "+x"])
+def test_fused_operator_carries_the_ultra_local_loop(hip, prec, order, lengths, dispstr):
+    """mugiq_hip_displaced_loop_contraction_fused_carry: where the tiled kernel has room (a free slot of its 12-wave forms, the
+    fourth slot of the 16-wave fp64 FLOAT2 form) the ultra-local loop comes out of the same pass and equals the loop of
+    performLoopContractionBatched; where it has not, `carried` is False and the slot is left alone.  The displaced slots are the
+    same either way."""
+    X, nev = (8, 8, 4, 8), 5
+    ev, Uo, f, U = _setup(hip, X, nev, prec, order, 99)
+    sg = sigmas(nev)
+    dirn, sign = orc.parse_displacement(dispstr)
+    V = int(np.prod(X))
+    cdt = torch.complex128 if prec == 8 else torch.complex64
+    E = [hip.SpinorField(X, prec, 2) for _ in range(max(lengths) + 1)]
+    ident = np.zeros((2, V // 2, 4, 3), dtype=np.complex128)
+    for s_ in range(3):
+        ident[:, :, s_, s_] = 1.0
+    E[0].set_logical(ident)
+    for k in range(1, len(E)):
+        hip.performCovariantDisplacementVector(E[k], E[k - 1], U, dirn, sign)
+    links = [E[k] for k in lengths]
+    plain = torch.zeros(len(lengths) * 16 * V, dtype=cdt, device="cuda")
+    hip.displacedLoopContractionFused(plain, f, sg, links, lengths, dirn, sign)
+    both = torch.zeros_like(plain)
+    ultra = torch.full((16 * V,), 7.0, dtype=cdt, device="cuda")       # (accumulated into: the 7 must survive underneath)
+    carried = hip.displacedLoopContractionFused(both, f, sg, links, lengths, dirn, sign, ultraLocalSlot_d=ultra)
+    assert torch.equal(both, plain)
+    if carried:
+        ref = torch.full((16 * V,), 7.0, dtype=cdt, device="cuda")
+        hip.performLoopContractionBatched(ref, f, f, sg)
+        tol = 1e-13 if prec == 8 else 1e-5
+        assert rel_err(ultra.cpu().numpy(), ref.cpu().numpy()) < tol
+    else:
+        assert torch.all(ultra == 7.0)
+    if prec == 8 and order == 2 and dirn >= 1:
+        assert carried                                     # the forms this was built for: fp64 FLOAT2 column tiles, up to three lengths
+
+
 @pytest.mark.parametrize("grid,prec,order,calc", [((1, 1, 1, 2), 8, 2, 1), ((1, 1, 2, 1), 8, 4, 1), ((1, 1, 1, 2), 8, 2, 2),
                                                   ((1, 1, 2, 1), 4, 4, 2), ((2, 1, 1, 1), 4, 2, 1), ((1, 2, 1, 1), 8, 2, 2)])
 def test_two_rank_driver_on_one_gpu(grid, prec, order, calc):
@@ -460,16 +498,19 @@ def test_driver_mg_coarse_path_random(hip, seed, record_max):
 
 
 @pytest.mark.parametrize("X", [(4, 8, 4, 8), (8, 4, 4, 8), (6, 4, 12, 4), (16, 4, 4, 4), (12, 8, 4, 4)])
-@pytest.mark.parametrize("tile", ["0", "1", "cols16", "cols32", "regs"])
+@pytest.mark.parametrize("tile", ["0", "1", "cols16", "cols32", "regs", "nocarry"])
 def test_fused_plans_agree_tiled_and_streaming(hip, tile, X, monkeypatch):
     """The LDS-tiled kernels (csrc/fused_tile.hip: 32-line positions; csrc/fused_tile16.hip: 16-line items, by default only
     for x rows that do not fill 32-line positions) and the first-generation streaming kernel are implementations of the same
     entry point: each must match the oracle.  cols16 / cols32 force one tiled generation for everything it can take; regs
-    stages the fp64 column tiles through registers instead of global -> LDS transfers (MUGIQ_HIP_TILE_GLDS=0)."""
+    stages the fp64 column tiles through registers instead of global -> LDS transfers (MUGIQ_HIP_TILE_GLDS=0); nocarry keeps the
+    ultra-local loop in a pass of its own."""
     if tile.startswith("cols"):
         monkeypatch.setenv("MUGIQ_HIP_TILE_COLS", tile[4:])
     elif tile == "regs":
         monkeypatch.setenv("MUGIQ_HIP_TILE_GLDS", "0")
+    elif tile == "nocarry":                        # the ultra-local loop in its own pass (by default it rides along with an entry)
+        monkeypatch.setenv("MUGIQ_HIP_CARRY_ULTRALOCAL", "0")
     else:
         monkeypatch.setenv("MUGIQ_HIP_FUSED_TILE", tile)
     nev = 3
