@@ -263,7 +263,7 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
             t = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t[0])
-        rec = {"seconds": el, "phases": loop.phases(), "nLoop": loop.nLoop,
+        rec = {"seconds": el, "phases": loop.phases(), "nLoop": loop.nLoop, "carrier": loop.ultraLocalCarrier(),
                "derived": [loop.derivedFrom(i) for i in range(loop.nDispEntries)],
                "entries": [loop.entry(i) for i in range(loop.nDispEntries)]}
         loop.close()
@@ -283,8 +283,10 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
         tag = "entry_%s%s" % ("+" if e[1] == 1 else "-", names[e[0]])
         ms_f = phase_sum(ph, "entry_fused", i)
         if ms_f > 0:
-            out["roofline"][tag] = roof("fp64_vector", ("tile16_displaced_contract_kernel<DIR=0> (row tile, 16-line items)" if e[0] == 0 else "tile_displaced_contract_kernel (column tile)"),
-                                        ms_f, ent_bytes, ent_flops, note=CLOCK_NOTE)
+            carries = best["carrier"] == i   # this entry's pass also produced the ultra-local loop: + 48 complex FMAs per site and eigenvector, + its slot
+            out["roofline"][tag] = roof("fp64_vector", ("tile16_displaced_contract_kernel<DIR=0> (row tile, 16-line items)" if e[0] == 0 else
+                                                        "tile_displaced_contract_kernel (column tile)" + (", 16 waves: + the ultra-local loop as a fourth slot" if carries else "")),
+                                        ms_f, ent_bytes + (V * 32 * B if carries else 0), ent_flops + (V * nev * 48 * 8.0 if carries else 0), note=CLOCK_NOTE)
             if pmc_workload:
                 attach_traffic(out["roofline"][tag], ["displaced_contract_kernel<double, double, 2, %d, %d," % (e[0], e[1])])
         else:

@@ -465,6 +465,9 @@ int mugiq_hip_loop_get_entry(const MugiqHipLoop *loop, int id, int out6[6]);
 /* After mugiq_hip_loop_compute: the entry that entry `id` was reflected from (see mugiq_hip_reflect_displaced_loop), or
  * -1 if it was computed from the eigenvectors; -2 for a bad handle / index. */
 int mugiq_hip_loop_entry_derived_from(const MugiqHipLoop *loop, int id);
+/* After mugiq_hip_loop_compute: the displacement entry whose pass over the eigenvectors also produced the ultra-local loop
+ * (mugiq_hip_displaced_loop_contraction_fused_carry), or -1 if the ultra-local loop took a pass of its own. */
+int mugiq_hip_loop_ultra_local_carrier(const MugiqHipLoop *loop);
 /* Phase timing of a compute (measurement aid; off by default).  When switched on, mugiq_hip_loop_compute brackets each
  * phase with a pair of HIP events on the stream the phase runs on and, after its final synchronisation, reports the
  * device time between them.  Phases of different streams overlap in time (that is the point of the halo stream). */

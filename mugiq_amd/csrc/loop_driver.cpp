@@ -76,6 +76,7 @@ struct MugiqHipLoop_s {
   // OPT plan: the ultra-local loop rides along with one displaced entry when the tiled kernel has room for it (see
   // mugiq_hip_displaced_loop_contraction_fused_carry); ultraCarried says whether an entry of this compute has produced it
   bool carryUltra = false, ultraCarried = false;
+  int ultraCarrier = -1;  // the entry that took it along in the last compute, or -1
   // ---- MG coarse path (eigsolve->computeCoarse): coarse eigenvectors + one Transfer level (lib/loop_mugiq.cpp:277-319,482)
   bool coarseMode = false;
   std::vector<MugiqHipCoarseField> coarseVecs;
@@ -442,7 +443,10 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
                                                                  links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
                                                                  nullptr, 0, MUGIQ_HIP_REGION_ALL | ow, ultra, &carried, lp->stream)))
         return st;
-      if (carried) lp->ultraCarried = true;
+      if (carried) {
+        lp->ultraCarried = true;
+        lp->ultraCarrier = id;
+      }
       continue;
     }
     // pack the face layers -> [comm stream] exchange them  ||  [compute stream] interior sites -> boundary sites
@@ -921,6 +925,7 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
   lp->phases.clear();
   lp->eventsUsed = 0;
   lp->carryUltra = lp->ultraCarried = false;
+  lp->ultraCarrier = -1;
   const auto tWall0 = std::chrono::steady_clock::now();
   if (lp->coarseMode && lp->levelVecs.size() > 1) {
     // coarsest level -> level 1 through the upper transfer operators (lib/loop_mugiq.cpp:306-311), all eigenvectors per launch
@@ -1139,6 +1144,8 @@ int mugiq_hip_loop_get_entry(const MugiqHipLoop *lp, int id, int out6[6]) {
   out6[5] = lp->nLoopOffset[id];
   return MUGIQ_HIP_SUCCESS;
 }
+
+int mugiq_hip_loop_ultra_local_carrier(const MugiqHipLoop *lp) { return (lp && lp->computed) ? lp->ultraCarrier : -1; }
 
 int mugiq_hip_loop_entry_derived_from(const MugiqHipLoop *lp, int id) {
   if (!lp || id < 0 || id >= lp->nDispEntries) return -2;

@@ -232,6 +232,10 @@ class Loop_Mugiq:
         lengths), or -1 if it was computed from the eigenvectors."""
         return int(_lib.load().mugiq_hip_loop_entry_derived_from(self._handle, int(idx)))
 
+    def ultraLocalCarrier(self):
+        """After computeCoarseLoop: the entry whose pass over the eigenvectors also produced the ultra-local loop, or -1."""
+        return int(_lib.load().mugiq_hip_loop_ultra_local_carrier(self._handle))
+
     def setProfiling(self, on=True):
         """Bracket every phase of the next computeCoarseLoop with HIP events (mugiq_hip_loop_set_profiling)."""
         _lib.check(_lib.load().mugiq_hip_loop_set_profiling(self._handle, int(bool(on))))
