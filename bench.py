@@ -198,11 +198,11 @@ def source_fingerprint():
 
 
 def library_fingerprint():
-    """sha1 over every source of libmugiq_hip.so (tools/pmc_traffic_extra.py records the same)"""
+    """sha1 over the kernel sources of libmugiq_hip.so (tools/pmc_traffic_extra.py records the same)"""
     h = hashlib.sha1()
     d = os.path.join(ROOT, "mugiq_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".cpp", ".h")):
+        if f.endswith(".hip") or f == "internal.h":       # the kernels (the host-side driver does not change a kernel's traffic)
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:12]
 
