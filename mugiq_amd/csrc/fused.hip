@@ -388,6 +388,7 @@ int mugiq_hip_displaced_loop_contraction_fused_carry(void *loopData_d, int loopP
   MUGIQ_REQUIRE((region & 0xff) == MUGIQ_HIP_REGION_ALL || (region & 0xff) == MUGIQ_HIP_REGION_INTERIOR || (region & 0xff) == MUGIQ_HIP_REGION_BOUNDARY,
                 "%s: invalid region %d", who, region);
   MUGIQ_REQUIRE((region & ~(0xff | MUGIQ_HIP_REGION_OVERWRITE)) == 0, "%s: invalid region flags %d", who, region);
+  MUGIQ_REQUIRE(ultraLocalSlot_d == nullptr || carried != nullptr, "%s: ultraLocalSlot_d given without `carried` (the caller could not tell whether the slot was produced)", who);
   MUGIQ_REQUIRE(loopData_d && eVecs_h && sigma_h && pathLinkFields_h && kValues_h, "%s: NULL argument", who);
   MUGIQ_REQUIRE(nVec >= 1 && nK >= 1, "%s: nVec = %d, nK = %d must be >= 1", who, nVec, nK);
   MUGIQ_REQUIRE(dispDir >= 0 && dispDir < 4 && (dispSign == 0 || dispSign == 1), "%s: Got invalid dispDir and/or dispSign.", who);
