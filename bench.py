@@ -29,6 +29,7 @@ Usage: python bench.py --gpus N --steps K --warmup W        (N>1: launched by to
 """
 import argparse
 import hashlib
+import re
 import json
 import os
 import sys
@@ -188,12 +189,20 @@ def roof(bound, kernel, ms, alg_bytes=None, flops=None, note=None):
     return out
 
 
+def _normalised(path):
+    """source text without comments and with whitespace collapsed: a comment edit does not invalidate a PMC measurement"""
+    t = open(path, "r", errors="replace").read()
+    t = re.sub(r"/\*.*?\*/", " ", t, flags=re.S)
+    t = re.sub(r"//[^\n]*", " ", t)
+    return re.sub(r"\s+", " ", t).encode()
+
+
 def source_fingerprint():
     """sha1 over the sources of the headline kernel: a committed PMC measurement is attached to a bench line only if it was
     taken with the same kernel (tools/pmc_traffic.py records the same fingerprint)."""
     h = hashlib.sha1()
     for f in ("contract.hip", "internal.h"):
-        h.update(open(os.path.join(ROOT, "mugiq_amd", "csrc", f), "rb").read())
+        h.update(_normalised(os.path.join(ROOT, "mugiq_amd", "csrc", f)))
     return h.hexdigest()[:12]
 
 
@@ -203,7 +212,7 @@ def library_fingerprint():
     d = os.path.join(ROOT, "mugiq_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith(".hip") or f == "internal.h":       # the kernels (the host-side driver does not change a kernel's traffic)
-            h.update(open(os.path.join(d, f), "rb").read())
+            h.update(_normalised(os.path.join(d, f)))
     return h.hexdigest()[:12]
 
 

@@ -953,8 +953,8 @@ static int coarse_plan(const MugiqHipTransfer *T, const MugiqHipCoarseField *coa
 // (TCC_EA0_WRREQ against _64B).  Tried and dropped, all slower: non-temporal stores (51 ms); the x-neighbouring aggregates as
 // waves of one workgroup in step, so that the pieces of a line meet in L2 (28.8 ms); alternating the neighbours inside one
 // workgroup tile by tile (51 ms); aggregate pairs per wave with the 64-byte sector completed inside the store instruction
-// by a quad permutation (39.9 ms).  Every wait in the loop is vmcnt(0): loads and stores share that counter and complete out
-// of order with respect to each other, so a counted wait with stores in flight is not safe.
+// by a quad permutation (39.9 ms).  Every wait in the loop is vmcnt(0): loads and stores share that counter and are not
+// documented to complete in order with respect to each other, so no counted wait is used while stores are in flight.
 constexpr int kPmWaves = 8;  // waves per workgroup: even ones take chirality 0, odd ones chirality 1
 constexpr int kPmPairs = 4;  // eight-eigenvector blocks a wave keeps resident (measured: 12-16 blocks per pass beat 24 and 8)
 
@@ -1072,8 +1072,8 @@ template <int NV> __global__ __launch_bounds__(64 * kPmWaves) void prolong_mfma_
   fetch(0, Vs0);
   for (int rd = 0; rd < rounds; rd++) {
     const Cplx<double> *Vs = Vs0 + (rd & 1) * ROWS * LDV;
-    // my share of this round's tile has landed and my stores of the previous round have left (one counter for both, not in
-    // order with respect to each other: nothing short of zero is safe); after the barrier everybody's has, and nobody reads
+    // my share of this round's tile has landed and my stores of the previous round have left (one counter for both, with no
+    // documented order between the two kinds: zero is the safe wait); after the barrier everybody's has, and nobody reads
     // the other buffer any more
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

@@ -9,9 +9,18 @@ usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.c
 """
 import csv
 import hashlib
+import re
 import json
 import os
 import sys
+
+
+def _normalised(path):
+    """source text without comments and with whitespace collapsed: a comment edit does not invalidate a PMC measurement"""
+    t = open(path, "r", errors="replace").read()
+    t = re.sub(r"/\*.*?\*/", " ", t, flags=re.S)
+    t = re.sub(r"//[^\n]*", " ", t)
+    return re.sub(r"\s+", " ", t).encode()
 
 
 def source_fingerprint():
@@ -19,7 +28,7 @@ def source_fingerprint():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha1()
     for f in ("contract.hip", "internal.h"):
-        h.update(open(os.path.join(root, "mugiq_amd", "csrc", f), "rb").read())
+        h.update(_normalised(os.path.join(root, "mugiq_amd", "csrc", f)))
     return h.hexdigest()[:12]
 
 

@@ -9,11 +9,20 @@ usage: pmc_traffic_extra.py <fetch_counter_collection.csv> <write_counter_collec
 import collections
 import csv
 import hashlib
+import re
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _normalised(path):
+    """source text without comments and with whitespace collapsed: a comment edit does not invalidate a PMC measurement"""
+    t = open(path, "r", errors="replace").read()
+    t = re.sub(r"/\*.*?\*/", " ", t, flags=re.S)
+    t = re.sub(r"//[^\n]*", " ", t)
+    return re.sub(r"\s+", " ", t).encode()
 
 
 def library_fingerprint():
@@ -22,7 +31,7 @@ def library_fingerprint():
     d = os.path.join(ROOT, "mugiq_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith(".hip") or f == "internal.h":       # the kernels (the host-side driver does not change a kernel's traffic)
-            h.update(open(os.path.join(d, f), "rb").read())
+            h.update(_normalised(os.path.join(d, f)))
     return h.hexdigest()[:12]
 
 
