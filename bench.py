@@ -12,14 +12,20 @@ launch of loop_contract_kernel).  Inputs are synthetic (seeded Gaussian unit-nor
 
 N>1, headline: the lattice is block-partitioned over ranks (T first, then Z); the ultra-local contraction has no
 inter-site coupling, so ranks run independently on their local 32^4 block (weak scaling, no data-path
-collective); value = total sites / max-over-ranks time.
+collective); value = total sites / max-over-ranks time.  The line then also carries, at its top level, what the
+PARTITIONED configs[2] job did on the same ranks (`partitioned`: sites/s over all 25 slots, halo GB/s per rank, the halo wait
+the overlap did not hide), the process grid and the number of ranks RCCL saw (`nccl_ranks`).
+`python bench.py --gpus N` without a launcher starts its N ranks itself (children of this process, started before anything
+touches the GPU) and relays rank 0's line.
 
 After the timed region (not part of `value`; skipped with --no-extra) the other legs of the path are measured too and
 reported under `also_measured`, each with its own roofline block, timed by HIP events inside the driver
 (mugiq_hip_loop_set_profiling):
-  N = 1 : the configs[2]-shaped displaced-loop job on its per-GPU lattice (48.48.24.24, 8 entries x lengths 1..3, momentum
-          projection p^2 <= 9), the MG coarse loop of configs[4] (32^4, n_vec 24, N_ev 200), and the configs[3] per-GPU
-          ultra-local loop (64.64.32.16, fp32 storage / fp64 loops, N_ev 600).
+  N = 1 : the configs[2] job on its per-GPU lattice at the metric's N_ev = 400 (48.48.24.24, 8 entries x lengths 1..3,
+          momentum projection p^2 <= 9; 102 GB of eigenvectors), the same job with the partitioned code path FORCED on z and t
+          (configs[2]'s 1x1x2x4 grid seen from one rank, the rank being its own neighbour: packed halos, interior / boundary
+          tiles, halo buffers in HBM -- no xGMI), the MG coarse loop of configs[4] (32^4, n_vec 24, N_ev 200), and the
+          configs[3] per-GPU ultra-local loop (64.64.32.16, fp32 storage / fp64 loops, N_ev 600).
   N > 1 : the configs[2] job PARTITIONED over the ranks (T first, then Z: 1x1x1x2, 1x1x1x4, 1x1x2x4) through
           Loop_Mugiq + GridComm on nccl (= RCCL over xGMI): eigenvector halos posted ahead on a halo stream, interior tiles
           before the wait, boundary tiles after; halo bytes, transfer time and the interior / boundary split are reported.
@@ -29,9 +35,12 @@ Usage: python bench.py --gpus N --steps K --warmup W        (N>1: launched by to
 """
 import argparse
 import hashlib
+import copy
 import re
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -65,8 +74,8 @@ def parse():
     ap.add_argument("--no-extra", action="store_true",
                     help="only the headline (use this under `rocprofv3 --stats`: the extra legs launch the headline kernel with "
                          "other shapes and would blur its per-kernel average)")
-    ap.add_argument("--extra", default="", help="comma list restricting the extra legs: displaced,mg,cfg3 (N=1) / partitioned (N>1)")
-    ap.add_argument("--displaced-nev", type=int, default=100, help="eigenvectors of the displaced extra leg (configs[2] has 400: 102 GB)")
+    ap.add_argument("--extra", default="", help="comma list restricting the extra legs: displaced,forced,mg,cfg3 (N=1) / partitioned (N>1)")
+    ap.add_argument("--displaced-nev", type=int, default=400, help="eigenvectors of the displaced extra legs (configs[2]: 400 = 102 GB; 100 for a quick run)")
     ap.add_argument("--extra-timeout", type=float, default=420.0, help="watchdog for the extra legs (s); the headline line is printed anyway")
     # overrides of the partitioned leg (rehearsals on a one-GPU box: MUGIQ_BENCH_BACKEND=gloo and a small lattice)
     ap.add_argument("--part-lattice", type=int, nargs=4, default=None, help="LOCAL lattice of the partitioned leg")
@@ -137,11 +146,13 @@ def momenta_p2_le(n):
 # ---- CPU baseline ----------------------------------------------------------------------------------------------------
 def cpu_baseline(fields, sigmas, X, prec, order, budget_s):
     """Time the plain-C restatement of the reference kernel (oracle/mugiq_oracle.c, `port`) on the host cores,
-    on a bounded sample of the same workload: the first S even + S odd checkerboard sites of every eigenvector."""
+    on a bounded sample of the same workload: the first S even + S odd checkerboard sites of every eigenvector, S sized so
+    that every host thread gets >= 4096 sites; the sample is copied into place by the threads that read it (first touch)."""
     from oracle import c_oracle
     nev = len(fields)
     vcb = fields[0].volumeCB
-    S = min(vcb, 32768)                     # sample: 2*S sites x all N_ev eigenvectors
+    threads = c_oracle.num_threads()
+    S = min(vcb, max(32768, 2048 * threads))      # sample: 2*S sites x all N_ev eigenvectors
     cdt = np.complex128 if prec == 8 else np.complex64
     bufs = []
     for f in fields:
@@ -150,10 +161,11 @@ def cpu_baseline(fields, sigmas, X, prec, order, budget_s):
             h = d.view(2, 12, f.stride)[:, :, :S].contiguous().cpu().numpy()              # planes of S sites
         else:
             h = d.view(2, 6, f.stride, 2)[:, :, :S, :].contiguous().cpu().numpy()
-        bufs.append(np.ascontiguousarray(h.reshape(-1)).astype(cdt, copy=False))
+        h = np.ascontiguousarray(h.reshape(-1)).astype(cdt, copy=False)
+        bufs.append(c_oracle.first_touch_copy(h, 12 if order == 2 else 6, S))
+        del h
     loop = np.zeros(16 * 2 * S, dtype=cdt)
-    threads = c_oracle.num_threads()
-    c_oracle.loop_contract_native(loop, bufs, bufs, sigmas, S, S, 12 * S, order)        # warm-up pass
+    c_oracle.loop_contract_native(loop, bufs, bufs, sigmas, S, S, 12 * S, order)        # warm-up pass (first touch of `loop`)
     t0 = time.perf_counter()
     passes = 0
     while True:
@@ -165,8 +177,10 @@ def cpu_baseline(fields, sigmas, X, prec, order, budget_s):
             break
     sites_per_s = passes * 2 * S / el
     return {"value": sites_per_s, "unit": "sites/s", "cores": threads, "kind": "port",
-            "sample": "%d sites x %d eigenvectors (first %d checkerboard sites of each parity of the bench fields), "
-                      "%d passes in %.1f s, oracle/mugiq_oracle.c with OpenMP" % (2 * S, nev, S, passes, el)}, loop, S
+            "host_GBps": sites_per_s * nev * 24 * prec / 1e9,
+            "sample": "%d sites x %d eigenvectors (first %d checkerboard sites of each parity of the bench fields = %d sites per "
+                      "thread, pages first-touched by the reading threads), %d passes in %.1f s, oracle/mugiq_oracle.c with OpenMP, "
+                      "blocks of 8 sites" % (2 * S, nev, S, 2 * S // threads, passes, el)}, loop, S
 
 
 # ---- roofline helpers --------------------------------------------------------------------------------------------------
@@ -244,37 +258,46 @@ def phase_sum(phases, kind, entry=None):
 
 
 # ---- extra legs ----------------------------------------------------------------------------------------------------------
-def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backend="nccl"):
+def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backend="nccl", fields=None, gauge=None):
     """The configs[2] job through the driver's OPT plan: ultra-local + 8 entries x lengths 1..3 (25 slots), then the
     momentum projection onto p^2 <= p2max.  Returns the record with per-phase device times (best repetition)."""
     V = int(np.prod(X))
     B = prec
-    _, fields = make_evecs(hip, X, nev, prec, 2, device, seed=4242 + (comm.rank if comm else 0))
-    gauge = make_gauge(hip, X, prec, device, 20240501 + (comm.rank if comm else 0), comm)
+    multi = comm is not None and world > 1
+    if fields is None:
+        _, fields = make_evecs(hip, X, nev, prec, 2, device, seed=4242 + (comm.rank if comm else 0))
+    if gauge is None:
+        gauge = make_gauge(hip, X, prec, device, 20240501 + (comm.rank if comm else 0), comm)
     moms = momenta_p2_le(p2max)
     sig = 0.01 + 0.002 * np.arange(nev)
     best = None
     for r in range(reps + 1):                 # the first repetition warms the scratch pool up (hipMalloc of ~GB buffers)
         prm = hip.MugiqLoopParam(gauge=gauge, calcType=hip.LOOP_CALC_TYPE_OPT_KERNEL, doMomProj=True, momMatrix=moms,
                                  Nmom=len(moms), FTSign=-1).set_displace_entry_string(ENTRIES_CFG2)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
         loop = hip.Loop_Mugiq(prm, fields, sig, comm).setProfiling()
-        if comm is not None:
+        torch.cuda.synchronize()
+        create_s = time.perf_counter() - tc       # buffers (loop slots, the halo buffers of the plan), phase matrix: the constructor's work
+        if multi:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         loop.computeCoarseLoop()
         torch.cuda.synchronize()
-        if comm is not None:
+        if multi:
             dist.barrier()
         el = time.perf_counter() - t0
-        if comm is not None:
+        if multi:
             t = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t[0])
+        free_b, total_b = torch.cuda.mem_get_info(device)
         rec = {"seconds": el, "phases": loop.phases(), "nLoop": loop.nLoop, "carrier": loop.ultraLocalCarrier(),
                "derived": [loop.derivedFrom(i) for i in range(loop.nDispEntries)],
-               "entries": [loop.entry(i) for i in range(loop.nDispEntries)]}
+               "entries": [loop.entry(i) for i in range(loop.nDispEntries)],
+               "device_bytes_in_use": int(total_b - free_b), "create_seconds": create_s}      # eigenvectors + links + loop buffers + the driver's scratch / halo pool
         loop.close()
         if r > 0 and (best is None or el < best["seconds"]):
             best = rec
@@ -284,7 +307,9 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
     ent_bytes = V * (nev * 24 * B + nslot * (24 * B + 32 * B))                 # eigenvectors once + W_k once + slots written once
     ent_flops = V * nev * nslot * (36 + 48) * 8.0                               # SU(3) x spinor + colour-traced outer product, complex FMAs
     out = {"seconds": best["seconds"], "sites_per_s_all_slots": world * V / best["seconds"], "n_loop_slots": best["nLoop"],
-           "entries_reflected": sum(1 for d in best["derived"] if d >= 0), "roofline": {}}
+           "entries_reflected": sum(1 for d in best["derived"] if d >= 0), "device_bytes_in_use": best["device_bytes_in_use"],
+           "create_seconds": best["create_seconds"],
+           "roofline": {}}
     names = ["x", "y", "z", "t"]
     for i, e in enumerate(best["entries"]):
         if best["derived"][i] >= 0:
@@ -331,18 +356,51 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
     halo = [p for p in ph if p["kind"] == "halo_transfer"]
     if halo:
         hb, hms = sum(p["bytes"] for p in halo), sum(p["ms"] for p in halo)
+        pms = phase_sum(ph, "halo_prepare")
         out["halo"] = {"bytes_sent_per_rank": hb, "transfer_ms": hms, "GBps_per_rank": hb / (hms * 1e-3) / 1e9 if hms > 0 else None,
-                       "prepare_ms": phase_sum(ph, "halo_prepare"), "wait_ms_not_hidden": phase_sum(ph, "halo_wait"),
-                       "messages": len(halo)}
+                       "prepare_ms": pms, "pack_GBps": 2 * hb / (pms * 1e-3) / 1e9 if pms > 0 else None,
+                       "wait_ms_not_hidden": phase_sum(ph, "halo_wait"), "messages": len(halo),
+                       "note": "pack_GBps counts the face layers read + written by pack_layers_kernel over the prepare phase "
+                               "(which also builds the path-link fields of the entry)"}
     out["phase_ms"] = {k: phase_sum(ph, k) for k in sorted(set(p["kind"] for p in ph))}
     return out
 
 
-def extra_displaced(hip, device, nev=100):
+_CFG2_INPUTS = {}
+
+
+def cfg2_inputs(hip, device, nev):
+    """The eigenvectors of the configs[2] per-GPU lattice, generated once and shared by the unpartitioned and the
+    forced-partition leg (102 GB at N_ev = 400)."""
+    if _CFG2_INPUTS.get("nev") != nev:
+        _CFG2_INPUTS.clear()
+        big, fields = make_evecs(hip, (48, 48, 24, 24), nev, 8, 2, device, seed=4242)
+        _CFG2_INPUTS.update({"nev": nev, "big": big, "fields": fields})
+    return _CFG2_INPUTS["fields"]
+
+
+def extra_displaced(hip, device, nev=400):
     X = (48, 48, 24, 24)
-    out = displaced_job(hip, device, X, nev, 8, None, 1)
+    out = displaced_job(hip, device, X, nev, 8, None, 1, fields=cfg2_inputs(hip, device, nev))
     out["workload"] = "48x48x24x24 fp64 N_ev=%d (configs[2] per-GPU lattice%s), entries %s, momentum projection p^2<=9, driver OPT plan" % (
         nev, "" if nev == 400 else ", N_ev reduced from 400", ENTRIES_CFG2)
+    return out
+
+
+def extra_forced(hip, device, nev=400):
+    """configs[2] as ONE rank of its 1x1x2x4 grid sees it: the partitioned code path forced on z and t with the rank as its own
+    forward and backward neighbour (MugiqHipComm.partitioned = QUDA's comm_dim_partitioned_set).  Everything the 8-GPU run does
+    on a rank happens here at full size -- gauge borders R = 2 through sendrecv, `stop` face layers of all eigenvectors packed
+    and posted ahead on the halo stream, interior tiles before the halo event, boundary tiles after, halos of the reflected
+    slots -- except that the message is a device copy instead of an xGMI transfer."""
+    X = (48, 48, 24, 24)
+    fields = cfg2_inputs(hip, device, nev)
+    comm = hip.GridComm((1, 1, 1, 1), device=device, force_partitioned=(0, 0, 1, 1))
+    gauge = make_gauge(hip, X, 8, device, 20240501, comm)
+    out = displaced_job(hip, device, X, nev, 8, comm, 1, reps=1, fields=fields, gauge=gauge)
+    out["workload"] = "48x48x24x24 fp64 N_ev=%d, z and t FORCED-partitioned on one rank (self-neighbour: device copies, no xGMI), " \
+                      "entries %s, momentum projection p^2<=9, driver OPT plan, halos posted ahead" % (nev, ENTRIES_CFG2)
+    out["forced_partition"] = [0, 0, 1, 1]
     return out
 
 
@@ -453,14 +511,37 @@ def extra_partitioned(hip, device, a, world, rank, backend):
 
 
 # ---- main --------------------------------------------------------------------------------------------------------------
+def self_launch(a):
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as CHILDREN (python -m torch.distributed.run)
+    before this process has touched the GPU, relay rank 0's JSON line, exit with the launcher's status.  (Never exec: a process
+    that has initialised the GPU must not be replaced.)"""
+    backend = os.environ.get("MUGIQ_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if backend == "nccl" and ndev < a.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible (RCCL needs one device per rank; MUGIQ_BENCH_BACKEND=gloo "
+                         "rehearses N ranks on fewer devices)" % (a.gpus, ndev))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:                 # rank 0's line goes to stdout, anything else the ranks print to stderr
+        (sys.stdout if line.startswith('{"metric"') else sys.stderr).write(line)
+        sys.stdout.flush()
+    raise SystemExit(child.wait())
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE = %d" % (a.gpus, world))
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
@@ -512,13 +593,26 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     # ---------------------------------------------------------------------------------------------------
-    kern_ms = float(np.mean([ev0[i].elapsed_time(ev1[i]) for i in range(a.steps)]))
+    step_ms = np.array([ev0[i].elapsed_time(ev1[i]) for i in range(a.steps)])
+    kern_ms = float(np.median(step_ms))                                  # median of the per-launch event times
     t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = float(t[0]), float(t[1])
     ms_per_step = elapsed * 1e3 / a.steps
     value = world * V / (ms_per_step * 1e-3)
+
+    # what this device streams right now: a pure 16-B/lane non-temporal read of the SAME eigenvector buffer, same process,
+    # straight after the timed region (tells a slow kernel from slow memory when a box runs off the usual numbers)
+    probe_ms = []
+    for r in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        hip.probeReadBandwidth(big, 1)
+        e1.record()
+        torch.cuda.synchronize()
+        probe_ms.append(e0.elapsed_time(e1))
+    probe_gbs = big.numel() * big.element_size() / (float(np.median(probe_ms[1:])) * 1e-3) / 1e9
 
     alg_bytes = V * (nev * 24 * B + 32 * lprec)      # per site N_ev*24*B read + 32*B written
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -534,7 +628,8 @@ def main():
             tj = json.load(open(tfile))
             if tj.get("workload") == workload and tj.get("source_fingerprint") == source_fingerprint():
                 traffic = tj.get("hbm_bytes_per_launch")
-                traffic_source = "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel sources %s)" % tj.get("source_fingerprint")
+                traffic_source = "NOT measured in this run: profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
+                                 "this workload, kernel sources %s = the ones running here)" % tj.get("source_fingerprint")
         except Exception:
             traffic = None
 
@@ -546,8 +641,18 @@ def main():
                    "site_evecs_per_s": value * nev, "partition": "independent site blocks, one per rank"},
         "roofline": {"bound": "hbm", "kernel": "loop_contract_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
+                     "kernel_ms_stats": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max()),
+                                         "mean": float(step_ms.mean()), "n": int(a.steps),
+                                         "note": "per-launch HIP event times of the timed steps on rank 0; kernel_ms = their median "
+                                                 "(max over ranks)"},
+                     "probe_GBps": probe_gbs, "frac_of_probe": achieved / probe_gbs,
+                     "probe_note": "probe = read_probe_kernel, 16-B non-temporal loads over the same eigenvector buffer, same process, "
+                                   "right after the timed region (median of 5)"},
     }
+    if world > 1:
+        out["backend"] = backend
+        out["nccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0   # ranks RCCL saw (0: rehearsal over another backend)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         base, cpu_loop, S = cpu_baseline(fields, sig, X, prec, order, a.cpu_seconds)
         # the same sample on the GPU result: the checker agrees with what was just timed
@@ -557,28 +662,36 @@ def main():
         out["cpu_baseline"] = base
 
     # ---- extra legs: never part of `value`; a failure or a hang there must not cost the headline line ----------------------
+    lock = threading.Lock()
     printed = threading.Event()
+    running = {"leg": None}
 
     def emit():
-        if not printed.is_set():
-            printed.set()
-            if rank == 0:
-                print(json.dumps(out), flush=True)
+        with lock:
+            if not printed.is_set():
+                printed.set()
+                if rank == 0:
+                    print(json.dumps(out), flush=True)
 
     if not a.no_extra:
         del fields, big, loop
         torch.cuda.empty_cache()
         want = [w for w in a.extra.split(",") if w]
         legs = ([("displaced_loops", "displaced", lambda: extra_displaced(hip, device, a.displaced_nev)),
+                 ("forced_partition_displaced_loops", "forced", lambda: extra_forced(hip, device, a.displaced_nev)),
                  ("mg_coarse_loop", "mg", lambda: extra_mg(hip, device)),
                  ("cfg3_mixed_precision_ultra_local", "cfg3", lambda: extra_cfg3(hip, device))] if world == 1 else
                 [("partitioned_displaced_loops", "partitioned", lambda: extra_partitioned(hip, device, a, world, rank, backend))])
-        out["also_measured"] = {}
+        also = {}
+        out["also_measured"] = also
 
         def on_timeout():
-            out["also_measured"]["error"] = "extra legs did not finish within %.0f s; headline unaffected" % a.extra_timeout
+            # a leg hung (or is far slower than it should be): the headline line is still printed, but the process reports
+            # the failure -- status 3 and the name of the leg that was running -- so that the hang is seen and can be traced
+            with lock:
+                also["error"] = "extra leg '%s' did not finish within %.0f s; headline unaffected; exit status 3" % (running["leg"], a.extra_timeout)
             emit()
-            os._exit(0)
+            os._exit(3)
 
         dog = threading.Timer(a.extra_timeout, on_timeout)
         dog.daemon = True
@@ -586,14 +699,29 @@ def main():
         for key, short, fn in legs:
             if want and short not in want:
                 continue
+            running["leg"] = key
+            if short not in ("displaced", "forced") and _CFG2_INPUTS:
+                _CFG2_INPUTS.clear()                      # the 102 GB of configs[2] eigenvectors are not needed any more
+                torch.cuda.empty_cache()
             try:
-                out["also_measured"][key] = fn()
+                res = fn()
             except Exception as e:                        # reported, not raised: the headline above stands on its own
-                out["also_measured"][key] = {"error": "%s: %s" % (type(e).__name__, e)}
-                if world > 1:
-                    break                                 # the ranks may be out of step: no further collective work
+                res = {"error": "%s: %s" % (type(e).__name__, e)}
+            with lock:
+                also[key] = res
+            if "error" in res and world > 1:
+                break                                     # the ranks may be out of step: no further collective work
             torch.cuda.empty_cache()
+        _CFG2_INPUTS.clear()
         dog.cancel()
+        pd = also.get("partitioned_displaced_loops")
+        if world > 1 and pd and "error" not in pd:
+            # the partitioned configs[2] job at the top level: what a scaling curve of THIS path would be drawn from
+            h = pd.get("halo", {})
+            out["process_grid"] = pd.get("grid")
+            out["partitioned"] = {"workload": pd["workload"], "seconds": pd["seconds"], "sites_per_s_all_slots": pd["sites_per_s_all_slots"],
+                                  "halo_bytes_sent_per_rank": h.get("bytes_sent_per_rank"), "halo_GBps_per_rank": h.get("GBps_per_rank"),
+                                  "wait_ms_not_hidden": h.get("wait_ms_not_hidden")}
     emit()
     if dist is not None:
         try:

@@ -238,7 +238,8 @@ int mugiq_hip_displaced_loop_contraction_fused_region(void *loopData_d, int loop
  * it rides along as one more slot (k = 0, W = 1) of the tiled kernel when that has room -- a free slot of its 12-wave forms, or
  * the fourth slot of the 16-wave form (fp64 FLOAT2 column tiles with three lengths) -- which saves the separate pass over all
  * eigenvectors.  *carried = 1 if the slot was produced, 0 if not (then nothing was written to it and the caller computes it
- * with mugiq_hip_perform_loop_contraction_batched).  ultraLocalSlot_d = NULL: plain _region call. */
+ * with mugiq_hip_perform_loop_contraction_batched).  The slot is produced for the whole lattice or not at all: with a
+ * region other than MUGIQ_HIP_REGION_ALL it is never taken along (*carried = 0).  ultraLocalSlot_d = NULL: plain _region call. */
 int mugiq_hip_displaced_loop_contraction_fused_carry(void *loopData_d, int loopPrecision,
                                                      const MugiqHipSpinorField *eVecs_h, const double *sigma_h, int nVec,
                                                      const void *const *pathLinkFields_h, const int *kValues_h, int nK,
@@ -377,10 +378,16 @@ typedef struct MugiqHipComm_s {
    * sendrecv as it comes. */
   int (*group_begin)(void *ctx);
   int (*group_end)(void *ctx, void *stream);
+  /* comm_dim_partitioned(d) beyond grid[d] > 1 (QUDA: comm_dim_partitioned_set(d), the `--partition` switch of its tests):
+   * non-zero on an axis of extent 1 runs the PARTITIONED code path along it -- ghost zones, face packing, halo messages,
+   * interior / boundary split, gauge borders from sendrecv -- with the rank as its own forward and backward neighbour, so
+   * the halo machinery can be exercised (and timed) at full per-GPU size on one device.  The result equals the
+   * unpartitioned one.  sendrecv must then be set even when size == 1.  Zero-initialise for the usual behaviour. */
+  int partitioned[4];
 } MugiqHipComm;
 
 /* exchangeGhostVec(ColorSpinorField *x), lib/contract_wrappers.cu:166-169 (x->exchangeGhost(QUDA_INVALID_PARITY, nFace = 1, 0)):
- * fill the depth-1 ghost zones v->ghost[d][0 | 1] of every partitioned dimension (comm->grid[d] > 1), both directions,
+ * fill the depth-1 ghost zones v->ghost[d][0 | 1] of every partitioned dimension (comm->grid[d] > 1 or comm->partitioned[d]), both directions,
  * through comm->sendrecv (one transfer group when the transport has group_begin / group_end).  The zones must be device
  * buffers of 2*12*faceCB complex each; comm == NULL (one process) is a no-op.  The faces are packed into the library's
  * per-stream workspace. */
@@ -484,7 +491,8 @@ int mugiq_hip_loop_ultra_local_carrier(const MugiqHipLoop *loop);
 #define MUGIQ_HIP_PHASE_HALO_WAIT 10           /* compute stream idle until the halo has landed (what the overlap did not hide) */
 #define MUGIQ_HIP_PHASE_MOMENTUM_COPY 11       /* dataMom_d -> pinned host */
 #define MUGIQ_HIP_PHASE_MOMENTUM_REDUCE 12     /* host: reduce over space ranks, gather over time ranks, broadcast (wall time) */
-#define MUGIQ_HIP_PHASE_TOTAL_WALL 13          /* host wall time of the whole mugiq_hip_loop_compute call */
+#define MUGIQ_HIP_PHASE_TOTAL_WALL 13          /* host wall time of the whole mugiq_hip_loop_compute call (always the last phase) */
+#define MUGIQ_HIP_PHASE_SCRATCH_ALLOC 14       /* host: hipMalloc of scratch / halo buffers the pool did not hold yet (wall time, bytes) */
 typedef struct MugiqHipLoopPhase_s {
   int kind;     /* MUGIQ_HIP_PHASE_* */
   int entry;    /* displacement entry the phase belongs to, or -1 */

@@ -141,6 +141,7 @@ struct MpiGrid {
     for (int d = 0; d < 4; d++) {
       c.grid[d] = comm_dim(d);
       c.coord[d] = comm_coord(d);
+      c.partitioned[d] = (comm_dim(d) == 1 && comm_dim_partitioned(d)) ? 1 : 0;  // QUDA's forced partitioning (self-neighbour)
     }
     c.sendrecv = &sendrecv;
     c.reduce_space = &reduce_space;
@@ -161,8 +162,17 @@ struct MpiGrid {
     const int to = comm_rank_displaced(comm_default_topology(), disp);  // [QUDA-API]
     disp[dim] = -dir;
     const int from = comm_rank_displaced(comm_default_topology(), disp);
-    return MPI_Sendrecv(s, static_cast<int>(n), MPI_BYTE, to, dim, r, static_cast<int>(n), MPI_BYTE, from, dim, MPI_COMM_WORLD,
-                        MPI_STATUS_IGNORE);  // messages above 2 GiB: split (MPI counts are int)
+    // MPI counts are int: the OPT plan posts the whole multi-layer halo of all eigenvectors as ONE message (12.7 GB at
+    // configs[2]), so it goes out in pieces of at most 1 GiB -- same order on both sides, the pairing is preserved
+    const size_t piece = size_t(1) << 30;
+    const char *sp = static_cast<const char *>(s);
+    char *rp = static_cast<char *>(r);
+    for (size_t off = 0; off < n; off += piece) {
+      const int m = static_cast<int>(n - off < piece ? n - off : piece);
+      const int st = MPI_Sendrecv(sp + off, m, MPI_BYTE, to, dim, rp + off, m, MPI_BYTE, from, dim, MPI_COMM_WORLD, MPI_STATUS_IGNORE);
+      if (st != MPI_SUCCESS) return st;
+    }
+    return 0;
   }
   static int reduce_space(void *ctx, const void *s, void *r, size_t n, int prec) {  // lib/loop_mugiq.cpp:406
     return MPI_Reduce(s, r, static_cast<int>(n), T(prec), MPI_SUM, 0, static_cast<MpiGrid *>(ctx)->space);

@@ -34,16 +34,37 @@ def host_array(ptr, n_real, precision):
 
 
 class GridComm:
-    def __init__(self, grid, device=None):
+    def __init__(self, grid, device=None, force_partitioned=(0, 0, 0, 0)):
         """grid = ranks along (x, y, z, t).  torch.distributed must be initialised; every rank must construct this
-        (it creates the sub-groups collectively)."""
+        (it creates the sub-groups collectively).
+        force_partitioned[d] != 0 on an axis of extent 1: comm_dim_partitioned(d) is 1 there all the same (QUDA's
+        comm_dim_partitioned_set / `--partition`), i.e. the driver runs its partitioned code path along d -- ghost zones,
+        packed face layers, halo messages, interior / boundary tiles, gauge borders through sendrecv -- with this rank as
+        its own neighbour (the message is a device copy, or a send-to-self with loopback_through_transport).  It lets ONE
+        GPU run the halo machinery at the full per-GPU size; the result must equal the unpartitioned run."""
         self.grid = tuple(int(g) for g in grid)
+        self.force_partitioned = tuple(1 if f else 0 for f in force_partitioned)
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self._cb = None
+        self._group = None            # deferred (send, recv, staged recv target, dst, src) while a group is open
+        # A grid of extent 1 along `dim` makes a rank its own neighbour; the driver exchanges along such an axis only under
+        # forced partitioning, and sendrecv serves it with a device copy.  loopback_through_transport = True sends that
+        # message through the transport as well (a send to self inside one batch): ONE rank then exercises the real
+        # isend / irecv path of the backend.
+        self.loopback_through_transport = False
+        if not dist.is_initialized():
+            # one process without a process group: only the 1x1x1x1 grid, whose every message is a copy to self (forced
+            # partitioning on one device); the reduce / gather / bcast callbacks are never reached with size == 1
+            assert int(np.prod(self.grid)) == 1, "a process grid %s needs torch.distributed to be initialised" % (self.grid,)
+            self.size, self.rank, self.coord, self.backend = 1, 0, (0, 0, 0, 0), "local"
+            self.space_group = self.time_group = None
+            self.space_root, self.time_ranks, self.is_time_process = 0, [0], True
+            return
         self.size = dist.get_world_size()
         self.rank = dist.get_rank()
         assert int(np.prod(self.grid)) == self.size, "process grid %s does not match world size %d" % (self.grid, self.size)
         self.coord = self.coords_of(self.rank)
         self.backend = dist.get_backend()
-        self.device = torch.device(device) if device is not None else torch.device("cpu")
         # COMM_SPACE: ranks with equal t-coordinate, root = the one with x=y=z=0 (lowest world rank of the group)
         # COMM_TIME : ranks with x=y=z=0, ordered by t, root t=0                      lib/loop_mugiq.cpp:61-88
         self.space_group, self.space_root = None, None
@@ -55,12 +76,6 @@ class GridComm:
         self.time_ranks = [self.rank_of((0, 0, 0, t)) for t in range(self.grid[3])]
         self.time_group = dist.new_group(self.time_ranks)
         self.is_time_process = self.coord[:3] == (0, 0, 0)
-        self._cb = None
-        self._group = None            # deferred (send, recv, staged recv target, dst, src) while a group is open
-        # A grid of extent 1 along `dim` makes a rank its own neighbour; the driver never exchanges along such an axis, so
-        # sendrecv serves it with a local copy.  loopback_through_transport = True sends that message through the transport
-        # as well (a send to self inside one batch): it lets ONE rank exercise the real isend/irecv path of the backend.
-        self.loopback_through_transport = False
 
     # ---- topology (QUDA's comm_rank_from_coords: x slowest, t fastest) --------------------------------------
     def coords_of(self, rank):
@@ -76,7 +91,7 @@ class GridComm:
         return ((c[0] * gy + c[1]) * gz + c[2]) * gt + c[3]
 
     def comm_dim_partitioned(self, d):
-        return 1 if self.grid[d] > 1 else 0
+        return 1 if (self.grid[d] > 1 or self.force_partitioned[d]) else 0
 
     def neighbour(self, dim, direction):
         c = list(self.coord)
@@ -88,19 +103,19 @@ class GridComm:
         """Send `send` to the neighbour at coord[dim]+direction, receive `recv` from coord[dim]-direction.
         Tensors may live on the GPU; with a CPU-only backend (gloo) they are staged through host memory."""
         dst, src = self.neighbour(dim, direction), self.neighbour(dim, -direction)
+        if dst == self.rank and not self.loopback_through_transport:
+            # extent 1 along `dim` (forced partitioning): my own face is my ghost zone -- a copy on the current stream
+            recv.copy_(send, non_blocking=True)
+            return
         stage = self.backend == "gloo" and send.is_cuda
         s = send.cpu() if stage else send
         r = torch.empty_like(recv, device="cpu") if stage else recv
-        local = dst == self.rank and not self.loopback_through_transport
-        if self._group is not None and not local:
+        if self._group is not None:
             self._group.append((s, r, recv if stage else None, dst, src))     # issued together at group_end
             return
-        if local:                                 # grid of 1 in this dim (not called by the driver) -> periodic copy
-            r.copy_(s)
-        else:
-            ops = [dist.P2POp(dist.isend, s, dst), dist.P2POp(dist.irecv, r, src)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        ops = [dist.P2POp(dist.isend, s, dst), dist.P2POp(dist.irecv, r, src)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
         if stage:
             recv.copy_(r)
 
@@ -224,7 +239,7 @@ class GridComm:
             _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("size", ctypes.c_int),
                         ("grid", ctypes.c_int * 4), ("coord", ctypes.c_int * 4),
                         ("sendrecv", SENDRECV), ("reduce_space", REDUCE), ("gather_time", REDUCE), ("bcast", BCAST),
-                        ("group_begin", GBEGIN), ("group_end", GEND)]
+                        ("group_begin", GBEGIN), ("group_end", GEND), ("partitioned", ctypes.c_int * 4)]
 
         fns = (SENDRECV(guard(c_sendrecv)), REDUCE(guard(c_reduce)), REDUCE(guard(c_gather)), BCAST(guard(c_bcast)),
                GBEGIN(guard(c_group_begin)), GEND(guard(c_group_end)))
@@ -234,6 +249,7 @@ class GridComm:
         for d in range(4):
             c.grid[d] = self.grid[d]
             c.coord[d] = self.coord[d]
+            c.partitioned[d] = self.force_partitioned[d]
         c.sendrecv, c.reduce_space, c.gather_time, c.bcast, c.group_begin, c.group_end = fns
         self._cb = (c, fns)          # keep the callbacks alive
         return c

@@ -553,9 +553,13 @@ int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma,
   a.nJT = dir == 0 ? 1 : ev[0].X[dir] / kTileTJ;  // (the row tile is not cut along x: one "tile", or X0 = 2 would launch nothing)
   a.overwrite = (region & MUGIQ_HIP_REGION_OVERWRITE) ? 1 : 0;
   region &= 0xff;
+  // the ultra-local slot is produced for the WHOLE lattice or not at all: a launch restricted to the interior or the boundary
+  // tiles would write only part of it (and none of it where that region is empty), so it is taken along with REGION_ALL only
+  if (region != MUGIQ_HIP_REGION_ALL) ultra_d = nullptr;
   for (int k0 = 0; k0 < nK; k0 += kTileMaxSlots) {
     a.nslot = (nK - k0 < kTileMaxSlots) ? nK - k0 : kTileMaxSlots;
     a.kmax = 0;
+    bool withUltra = false;
     for (int s = 0; s < kTileCarry; s++) {
       const int i = k0 + (s < a.nslot ? s : 0);
       a.E[s] = static_cast<const F *>(E_d[i]);
@@ -569,7 +573,7 @@ int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma,
       a.k[a.nslot] = 0;
       a.out[a.nslot] = static_cast<Cplx<A> *>(ultra_d);
       a.nslot++;
-      if (carried) *carried = 1;
+      withUltra = true;
     }
     // region 0: everything | 1: tiles whose shifted reads stay inside the local lattice | 2: tiles that read ghost layers
     a.jtBegin = 0;
@@ -589,6 +593,7 @@ int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma,
     if (a.jtCount > 0) {
       st = launch_tile<F, A, ORDER>(a, dir, sign, stream);
       if (st) return st;
+      if (withUltra && carried) *carried = 1;  // only now: a launch that covers the whole lattice did write the slot
     }
   }
   return MUGIQ_HIP_SUCCESS;

@@ -102,7 +102,7 @@ static int fill_extended(const MugiqHipGaugeField *g, const void *const qdp[4], 
     };
     pack(sendLow, R[d]);          // first R interior layers  -> backward neighbour's HIGH border
     pack(sendHigh, X[d]);         // last  R interior layers  -> forward  neighbour's LOW border
-    const bool part = comm && comm->size > 1 && comm->grid[d] > 1;
+    const bool part = comm_partitioned(comm, d);
     if (part) {
       void *sd = nullptr, *rd = nullptr;
       const size_t bytes = n * sizeof(F);
@@ -194,19 +194,22 @@ int mugiq_hip_create_extended_gauge(const MugiqHipGaugeField *gauge, const void 
                 "%s: precisions must be 4 or 8", who);
   long long volEx = 1;
   int sumR = 0;
+  bool anyPart = false;
   for (int d = 0; d < 4; d++) {
     MUGIQ_REQUIRE(qdpLinks_h[d] != nullptr, "%s: host link pointer %d is NULL", who, d);
     MUGIQ_REQUIRE(gauge->X[d] > 0 && (gauge->X[d] & 1) == 0 && gauge->R[d] >= 0 && gauge->R[d] <= gauge->X[d],
                   "%s: invalid X[%d] = %d / R[%d] = %d", who, d, gauge->X[d], d, gauge->R[d]);
     volEx *= gauge->X[d] + 2 * gauge->R[d];
     sumR += gauge->R[d];
-    if (comm && comm->size > 1 && comm->grid[d] > 1)
+    if (comm_partitioned(comm, d)) {
+      anyPart = true;
       MUGIQ_REQUIRE(gauge->R[d] >= 1, "%s: dim %d is partitioned but R[%d] = 0", who, d, d);
+    }
   }
   MUGIQ_REQUIRE((sumR & 1) == 0, "%s: the sum of the borders R must be even", who);
   MUGIQ_REQUIRE(gauge->stride >= volEx / 2 && gauge->parity_offset >= (int64_t)36 * gauge->stride,
                 "%s: stride / parity_offset too small for the extended volume", who);
-  if (comm && comm->size > 1) MUGIQ_REQUIRE(comm->sendrecv != nullptr, "%s: comm->sendrecv is NULL", who);
+  if (anyPart) MUGIQ_REQUIRE(comm->sendrecv != nullptr, "%s: comm->sendrecv is NULL", who);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (gauge->precision == 8 && cpuPrecision == 8) return fill_extended<double, double>(gauge, qdpLinks_h, comm, s);
   if (gauge->precision == 8 && cpuPrecision == 4) return fill_extended<double, float>(gauge, qdpLinks_h, comm, s);

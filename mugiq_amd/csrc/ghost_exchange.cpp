@@ -15,7 +15,7 @@ extern "C" int mugiq_hip_exchange_ghost_vec(const MugiqHipSpinorField *v, const 
   hipStream_t s = static_cast<hipStream_t>(stream);
   size_t total = 0, bytes[4] = {0, 0, 0, 0};
   for (int d = 0; d < 4; d++) {
-    if (comm->grid[d] <= 1) continue;
+    if (!comm_partitioned(comm, d)) continue;
     MUGIQ_REQUIRE(v->ghost[d][0] != nullptr && v->ghost[d][1] != nullptr, "%s: dimension %d is partitioned but the field has no ghost zones for it", who, d);
     bytes[d] = (size_t)24 * (size_t)(v->volumeCB / v->X[d]) * 2 * (size_t)v->precision;
     total += 2 * bytes[d];
@@ -28,7 +28,7 @@ extern "C" int mugiq_hip_exchange_ghost_vec(const MugiqHipSpinorField *v, const 
   const bool grouped = comm->group_begin && comm->group_end;
   if (grouped && (st = comm->group_begin(comm->ctx))) return set_error(MUGIQ_HIP_ERROR_HIP, "%s: group_begin callback failed with status %d", who, st);
   for (int d = 0; d < 4; d++) {
-    if (comm->grid[d] <= 1) continue;
+    if (!comm_partitioned(comm, d)) continue;
     for (int high = 0; high < 2; high++) {
       // my low face is the backward neighbour's ghost[d][1] (forward zone); my high face the forward neighbour's ghost[d][0]
       if ((st = mugiq_hip_pack_face(send, v, d, high, stream))) return st;

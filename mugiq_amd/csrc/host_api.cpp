@@ -27,12 +27,23 @@ int set_error(int status, const char *fmt, ...) {
 // the kernel of call n), calls on different streams, threads or Loop objects never share a buffer.
 namespace {
 struct StreamArena {
-  void *tab = nullptr, *ws = nullptr, *pinned = nullptr;
-  size_t tabCap = 0, wsCap = 0, pinnedCap = 0;
-  hipEvent_t staged = nullptr;  // the last table has left the pinned staging buffer
+  std::mutex mtx;  // serialises the users of THIS arena (two host threads must not drive one stream anyway)
+  void *tab = nullptr, *ws = nullptr;
+  size_t tabCap = 0, wsCap = 0;
+  // two pinned staging buffers, used in turn: an upload waits for the upload TWO calls back to have left its buffer -- not for
+  // the previous one, which sits on the stream behind the previous call's kernel and would make every call a host sync
+  void *pinned[2] = {nullptr, nullptr};
+  size_t pinnedCap[2] = {0, 0};
+  hipEvent_t staged[2] = {nullptr, nullptr};
+  int turn = 0;
 };
-std::mutex g_arenaMtx;
+std::mutex g_arenaMtx;  // guards the map only; no HIP call is made while it is held
 std::map<std::pair<int, hipStream_t>, StreamArena> g_arenas;
+
+StreamArena &arena_of(int dev, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_arenaMtx);
+  return g_arenas[{dev, stream}];  // (std::map: the reference stays valid while other arenas come and go)
+}
 
 // grow-only buffer of an arena; the old buffer may still be read by kernels of THIS stream only, so that stream is drained
 int arena_reserve(void **buf, size_t *cap, size_t bytes, size_t floor, hipStream_t stream) {
@@ -57,8 +68,8 @@ int current_device(int *dev) {
 int stream_scratch(void **ptr, size_t bytes, hipStream_t stream) {
   int dev = 0, st = current_device(&dev);
   if (st) return st;
-  std::lock_guard<std::mutex> lock(g_arenaMtx);
-  StreamArena &a = g_arenas[{dev, stream}];
+  StreamArena &a = arena_of(dev, stream);
+  std::lock_guard<std::mutex> lock(a.mtx);
   if ((st = arena_reserve(&a.tab, &a.tabCap, bytes, 1u << 16, stream))) return st;
   *ptr = a.tab;
   return MUGIQ_HIP_SUCCESS;
@@ -67,8 +78,8 @@ int stream_scratch(void **ptr, size_t bytes, hipStream_t stream) {
 int stream_workspace(void **ptr, size_t bytes, hipStream_t stream) {
   int dev = 0, st = current_device(&dev);
   if (st) return st;
-  std::lock_guard<std::mutex> lock(g_arenaMtx);
-  StreamArena &a = g_arenas[{dev, stream}];
+  StreamArena &a = arena_of(dev, stream);
+  std::lock_guard<std::mutex> lock(a.mtx);
   if ((st = arena_reserve(&a.ws, &a.wsCap, bytes, 256, stream))) return st;
   *ptr = a.ws;
   return MUGIQ_HIP_SUCCESS;
@@ -77,22 +88,24 @@ int stream_workspace(void **ptr, size_t bytes, hipStream_t stream) {
 int upload_table(void **dev_out, const void *host, size_t bytes, hipStream_t stream) {
   int dev = 0, st = current_device(&dev);
   if (st) return st;
-  std::lock_guard<std::mutex> lock(g_arenaMtx);
-  StreamArena &a = g_arenas[{dev, stream}];
+  StreamArena &a = arena_of(dev, stream);
+  std::lock_guard<std::mutex> lock(a.mtx);
   if ((st = arena_reserve(&a.tab, &a.tabCap, bytes, 1u << 16, stream))) return st;
-  if (!a.staged) MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&a.staged, hipEventDisableTiming));
-  else MUGIQ_CHECK_HIP(hipEventSynchronize(a.staged));  // previous table has left the staging buffer
-  if (bytes > a.pinnedCap) {
-    if (a.pinned) MUGIQ_CHECK_HIP(hipHostFree(a.pinned));
-    a.pinned = nullptr;
-    a.pinnedCap = 0;
+  const int i = a.turn;
+  a.turn ^= 1;
+  if (!a.staged[i]) MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&a.staged[i], hipEventDisableTiming));
+  else MUGIQ_CHECK_HIP(hipEventSynchronize(a.staged[i]));  // the table of two calls back has left this staging buffer
+  if (bytes > a.pinnedCap[i]) {
+    if (a.pinned[i]) MUGIQ_CHECK_HIP(hipHostFree(a.pinned[i]));
+    a.pinned[i] = nullptr;
+    a.pinnedCap[i] = 0;
     const size_t want = bytes < (1u << 16) ? (1u << 16) : bytes * 2;
-    MUGIQ_CHECK_HIP(hipHostMalloc(&a.pinned, want, hipHostMallocDefault));
-    a.pinnedCap = want;
+    MUGIQ_CHECK_HIP(hipHostMalloc(&a.pinned[i], want, hipHostMallocDefault));
+    a.pinnedCap[i] = want;
   }
-  memcpy(a.pinned, host, bytes);
-  MUGIQ_CHECK_HIP(hipMemcpyAsync(a.tab, a.pinned, bytes, hipMemcpyHostToDevice, stream));
-  MUGIQ_CHECK_HIP(hipEventRecord(a.staged, stream));
+  memcpy(a.pinned[i], host, bytes);
+  MUGIQ_CHECK_HIP(hipMemcpyAsync(a.tab, a.pinned[i], bytes, hipMemcpyHostToDevice, stream));
+  MUGIQ_CHECK_HIP(hipEventRecord(a.staged[i], stream));
   *dev_out = a.tab;
   return MUGIQ_HIP_SUCCESS;
 }
@@ -100,16 +113,26 @@ int upload_table(void **dev_out, const void *host, size_t bytes, hipStream_t str
 int release_stream_scratch(hipStream_t stream) {
   int dev = 0, st = current_device(&dev);
   if (st) return st;
-  std::lock_guard<std::mutex> lock(g_arenaMtx);
-  auto it = g_arenas.find({dev, stream});
-  if (it == g_arenas.end()) return MUGIQ_HIP_SUCCESS;
+  StreamArena *ap = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_arenaMtx);
+    auto it = g_arenas.find({dev, stream});
+    if (it == g_arenas.end()) return MUGIQ_HIP_SUCCESS;
+    ap = &it->second;
+  }
   MUGIQ_CHECK_HIP(hipStreamSynchronize(stream));
-  StreamArena &a = it->second;
-  if (a.tab) (void)hipFree(a.tab);
-  if (a.ws) (void)hipFree(a.ws);
-  if (a.pinned) (void)hipHostFree(a.pinned);
-  if (a.staged) (void)hipEventDestroy(a.staged);
-  g_arenas.erase(it);
+  {
+    StreamArena &a = *ap;
+    std::lock_guard<std::mutex> lock(a.mtx);
+    if (a.tab) (void)hipFree(a.tab);
+    if (a.ws) (void)hipFree(a.ws);
+    for (int i = 0; i < 2; i++) {
+      if (a.pinned[i]) (void)hipHostFree(a.pinned[i]);
+      if (a.staged[i]) (void)hipEventDestroy(a.staged[i]);
+    }
+  }
+  std::lock_guard<std::mutex> lock(g_arenaMtx);
+  g_arenas.erase({dev, stream});
   return MUGIQ_HIP_SUCCESS;
 }
 

@@ -264,6 +264,9 @@ template <typename F> struct GaugeView {
 };
 
 int validate_spinor(const MugiqHipSpinorField *f, const char *who, const char *name);
+// comm_dim_partitioned(d) (include/contract_util.cuh:89): more than one rank along d, or the partitioned code path forced
+// on an axis of extent 1 (the rank is then its own neighbour; QUDA's comm_dim_partitioned_set)
+inline bool comm_partitioned(const MugiqHipComm *c, int d) { return c != nullptr && (c->grid[d] > 1 || c->partitioned[d] != 0); }
 bool same_geometry(const MugiqHipSpinorField &a, const MugiqHipSpinorField &b);
 
 }  // namespace mugiq

@@ -176,7 +176,11 @@ static int scratch_alloc(MugiqHipLoop *lp, void **p, size_t bytes, bool zero) {
     if (!lp->pool[i].inUse && lp->pool[i].bytes >= bytes && (best < 0 || lp->pool[i].bytes < lp->pool[best].bytes)) best = (int)i;
   if (best < 0) {
     void *q = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     MUGIQ_CHECK_HIP(hipMalloc(&q, bytes ? bytes : 16));
+    if (lp->profiling)
+      lp->phases.push_back({MUGIQ_HIP_PHASE_SCRATCH_ALLOC, -1, (double)bytes,
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), -1, -1});
     lp->pool.push_back({q, bytes, false});
     best = (int)lp->pool.size() - 1;
   }
@@ -329,6 +333,66 @@ static int build_path_links(MugiqHipLoop *lp, int id, std::vector<MugiqHipSpinor
   return MUGIQ_HIP_SUCCESS;
 }
 
+// bytes of the multi-layer eigenvector halo of entry `id` (one direction): `stop` face layers of all eigenvectors
+static size_t halo_bytes(const MugiqHipLoop *lp, int id) {
+  return (size_t)lp->dispStop[id] * 24 * (size_t)(lp->volumeCB / lp->localL[lp->dispDir[id]]) * lp->cplxBytes() * (size_t)lp->nEv;
+}
+
+static int reflection_source(const MugiqHipLoop *lp, int id);
+
+// The OPT plan: which entries are reflected from which (derivedFrom), and which of the computed entries along partitioned axes
+// get their eigenvector halo posted AHEAD, at the start of the compute (ahead[id] = 1).  The ghost-layer buffers posted ahead
+// may take a quarter of the device memory.  The rule must not depend on anything that can differ between ranks (such as the
+// memory free right now): every rank has to take the same decision, or the transfers would not pair up.
+static int plan_opt(MugiqHipLoop *lp, std::vector<char> &ahead) {
+  ahead.assign(lp->nDispEntries, 0);
+  for (int id = 0; id < lp->nDispEntries; id++) {
+    lp->derivedFrom[id] = -1;  // entries after `id` are still -1 here: reflection_source only looks at jd < id
+    lp->derivedFrom[id] = reflection_source(lp, id);
+  }
+  size_t freeB = 0, totalB = 0;
+  MUGIQ_CHECK_HIP(hipMemGetInfo(&freeB, &totalB));
+  size_t budget = totalB / 4;
+  if (const char *e = getenv("MUGIQ_HIP_HALO_AHEAD"))
+    if (atoi(e) == 0) budget = 0;
+  for (int id = 0; id < lp->nDispEntries; id++) {
+    const int dir = lp->dispDir[id];
+    if (lp->derivedFrom[id] >= 0 || !lp->commDim[dir] || lp->dispStop[id] > lp->localL[dir]) continue;
+    const size_t bytes = halo_bytes(lp, id);
+    if (2 * bytes > budget) continue;  // this entry exchanges eigenvector blocks of <= 4 GiB inside its own turn instead
+    budget -= 2 * bytes;
+    ahead[id] = 1;
+  }
+  return MUGIQ_HIP_SUCCESS;
+}
+
+// a buffer of `bytes` into the pool, free for scratch_alloc to hand out (hipMalloc of multi-GB buffers costs ~40 ms per GB: the
+// driver maps and clears the pages -- so what the plan is known to need is allocated when the loop object is built, like the
+// reference's allocateDataMemory, lib/loop_mugiq.cpp:101-158, not inside the first compute)
+static int pool_reserve(MugiqHipLoop *lp, size_t bytes) {
+  void *q = nullptr;
+  MUGIQ_CHECK_HIP(hipMalloc(&q, bytes ? bytes : 16));
+  lp->pool.push_back({q, bytes, false});
+  return MUGIQ_HIP_SUCCESS;
+}
+
+static int reserve_plan_buffers(MugiqHipLoop *lp) {
+  if (lp->calcType == MUGIQ_HIP_LOOP_CALC_TYPE_BASIC_KERNEL || lp->nDispEntries == 0) return MUGIQ_HIP_SUCCESS;
+  std::vector<char> ahead;
+  int st = plan_opt(lp, ahead);
+  if (st) return st;
+  const size_t fieldB = (size_t)24 * lp->volumeCB * lp->cplxBytes();  // a FLOAT2 pad-0 path-link field
+  for (int id = 0; id < lp->nDispEntries; id++) {
+    if (!ahead[id]) continue;
+    const size_t faceB = (size_t)24 * (lp->volumeCB / lp->localL[lp->dispDir[id]]) * lp->cplxBytes();
+    for (int k = 0; k <= lp->dispStop[id]; k++)
+      if ((st = pool_reserve(lp, fieldB))) return st;  // E_0 .. E_stop, held until the entry has run
+    if ((st = pool_reserve(lp, faceB)) || (st = pool_reserve(lp, faceB))) return st;
+    if ((st = pool_reserve(lp, halo_bytes(lp, id))) || (st = pool_reserve(lp, halo_bytes(lp, id)))) return st;
+  }
+  return MUGIQ_HIP_SUCCESS;
+}
+
 static int ensure_comm_stream(MugiqHipLoop *lp) {
   if (!lp->commStream) {
     MUGIQ_CHECK_HIP(hipStreamCreateWithFlags(&lp->commStream, hipStreamNonBlocking));
@@ -339,13 +403,10 @@ static int ensure_comm_stream(MugiqHipLoop *lp) {
 }
 
 // Halo of entry `id` posted ahead, step 1: link fields (their small face exchanges happen here, at once), ghost buffers
-// for ALL eigenvectors, pack kernel.  Skipped (entry_fused then exchanges block by block in its own turn) when the
-// buffers would not fit `budget` bytes.
-static int prepare_halo(MugiqHipLoop *lp, int id, size_t *budget) {
+// for ALL eigenvectors, pack kernel.  (Whether an entry is posted ahead is plan_opt's decision.)
+static int prepare_halo(MugiqHipLoop *lp, int id) {
   const int dir = lp->dispDir[id], sign = lp->dispSign[id], stop = lp->dispStop[id];
-  const int faceCB = lp->volumeCB / lp->localL[dir];
-  const size_t bytes = (size_t)stop * 24 * faceCB * lp->cplxBytes() * (size_t)lp->nEv;
-  if (2 * bytes > *budget) return MUGIQ_HIP_SUCCESS;
+  const size_t bytes = halo_bytes(lp, id);
   int st;
   MugiqHipLoop::HaloPost &h = lp->halo[id];
   if (!h.evPacked) {
@@ -359,7 +420,6 @@ static int prepare_halo(MugiqHipLoop *lp, int id, size_t *budget) {
   // all of these outlive the entries processed in between: move them from the per-entry list to the held list
   for (void *q : lp->scratch) lp->held.push_back(q);
   lp->scratch.clear();
-  *budget -= 2 * bytes;
   const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
   if ((st = mugiq_hip_pack_face_layers(h.gsend, lp->eVecs.data(), lp->nEv, dir, high, stop, lp->stream))) return st;
   MUGIQ_CHECK_HIP(hipEventRecord(h.evPacked, lp->stream));
@@ -370,8 +430,8 @@ static int prepare_halo(MugiqHipLoop *lp, int id, size_t *budget) {
 
 // step 2: hand the packed layers to the transport on the halo stream (possibly inside a transfer group)
 static int send_halo(MugiqHipLoop *lp, int id) {
-  const int dir = lp->dispDir[id], sign = lp->dispSign[id], stop = lp->dispStop[id];
-  const size_t bytes = (size_t)stop * 24 * (lp->volumeCB / lp->localL[dir]) * lp->cplxBytes() * (size_t)lp->nEv;
+  const int dir = lp->dispDir[id], sign = lp->dispSign[id];
+  const size_t bytes = halo_bytes(lp, id);
   const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
   MugiqHipLoop::HaloPost &h = lp->halo[id];
   MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, h.evPacked, 0));
@@ -685,15 +745,18 @@ int mugiq_hip_loop_create(MugiqHipLoop **out, const MugiqHipLoopParam *p, const 
     lp->comm = *comm;
     lp->haveComm = true;
     long long prod = 1;
+    bool anyPart = false;
     for (int d = 0; d < 4; d++) {
       if (comm->grid[d] < 1 || comm->coord[d] < 0 || comm->coord[d] >= comm->grid[d]) {
         set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "%s: invalid comm grid/coord in dim %d", who, d);
         return fail(MUGIQ_HIP_ERROR_INVALID_ARGUMENT);
       }
-      lp->commDim[d] = comm->grid[d] > 1;
+      lp->commDim[d] = comm_partitioned(comm, d);
+      anyPart = anyPart || lp->commDim[d];
       prod *= comm->grid[d];
     }
-    if (prod != comm->size || (comm->size > 1 && (!comm->sendrecv || !comm->reduce_space || !comm->gather_time || !comm->bcast))) {
+    if (prod != comm->size || (comm->size > 1 && (!comm->sendrecv || !comm->reduce_space || !comm->gather_time || !comm->bcast)) ||
+        (anyPart && !comm->sendrecv)) {
       set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "%s: comm grid does not match comm size %d, or a callback is NULL", who, comm->size);
       return fail(MUGIQ_HIP_ERROR_INVALID_ARGUMENT);
     }
@@ -816,6 +879,8 @@ int mugiq_hip_loop_create(MugiqHipLoop **out, const MugiqHipLoopParam *p, const 
                                             lp->totalL, cc, lp->loopPrecision, lp->stream)))
       return fail(st);
   }
+  // the buffers the OPT plan will hold for the halos it posts ahead (the large allocations of a partitioned run)
+  if (lp->haveGauge && (st = reserve_plan_buffers(lp))) return fail(st);
   *out = lp;
   return MUGIQ_HIP_SUCCESS;
 }
@@ -954,36 +1019,24 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
     }
   } else {
     lp->halo.resize(lp->nDispEntries);
-    for (int id = 0; id < lp->nDispEntries; id++) {
-      lp->derivedFrom[id] = -1;  // entries after `id` are still -1 here: reflection_source only looks at jd < id
-      lp->derivedFrom[id] = reflection_source(lp, id);
-      lp->halo[id].posted = false;
-    }
-    // ghost-layer buffers posted ahead may take a quarter of the device memory.  The rule must not depend on anything
-    // that can differ between ranks (such as the memory free right now): every rank has to take the same decision, or
-    // the transfers would not pair up
-    size_t freeB = 0, totalB = 0;
-    MUGIQ_CHECK_HIP(hipMemGetInfo(&freeB, &totalB));
-    size_t budget = totalB / 4;
-    if (const char *e = getenv("MUGIQ_HIP_HALO_AHEAD"))
-      if (atoi(e) == 0) budget = 0;
-    const bool grouped = lp->haveComm && lp->comm.group_begin && lp->comm.group_end;
+    std::vector<char> ahead;
+    if ((st = plan_opt(lp, ahead))) return st;
     bool any = false;
-    for (int id = 0; id < lp->nDispEntries && budget > 0; id++)
-      any = any || (lp->derivedFrom[id] < 0 && lp->commDim[lp->dispDir[id]] && lp->dispStop[id] <= lp->localL[lp->dispDir[id]]);
+    for (int id = 0; id < lp->nDispEntries; id++) {
+      lp->halo[id].posted = false;
+      any = any || ahead[id];
+    }
+    const bool grouped = lp->haveComm && lp->comm.group_begin && lp->comm.group_end;
     if (any) {
       if ((st = ensure_comm_stream(lp))) return st;
-      for (int id = 0; id < lp->nDispEntries; id++) {
-        const int dir = lp->dispDir[id];
-        if (lp->derivedFrom[id] < 0 && lp->commDim[dir] && lp->dispStop[id] <= lp->localL[dir])
-          if ((st = prepare_halo(lp, id, &budget))) return st;
-      }
+      for (int id = 0; id < lp->nDispEntries; id++)
+        if (ahead[id] && (st = prepare_halo(lp, id))) return st;
       double haloBytes = 0;
       for (int id = 0; id < lp->nDispEntries; id++)
         if (lp->halo[id].posted) {
           // (the transfer cannot start before the last pack kernel: wait here so that the phase brackets the transfer only)
           MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, lp->halo[id].evPacked, 0));
-          haloBytes += (double)lp->dispStop[id] * 24 * (lp->volumeCB / lp->localL[lp->dispDir[id]]) * lp->cplxBytes() * (double)lp->nEv;
+          haloBytes += (double)halo_bytes(lp, id);
         }
       const int phHalo = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_TRANSFER, -1, lp->commStream, haloBytes);
       if (grouped && (st = lp->comm.group_begin(lp->comm.ctx))) return set_error(MUGIQ_HIP_ERROR_HIP, "group_begin callback failed with status %d", st);

@@ -1026,7 +1026,9 @@ template <int NV> __global__ __launch_bounds__(64 * kPmWaves) void prolong_mfma_
                              (int64_t)kq * a.nVec8 + (rowA & 3) + 4 * (rowA >> 3);
 #pragma unroll
     for (int i = 0; i < kPmPairs; i++) {
-      const int b = a.blkBegin + b0 + (i < npairs ? 4 * i : 0);  // (blocks past the last one shadow a valid one; they are never used)
+      // (blocks past the last one shadow a valid one -- block b0 of the wave, or the first block of the pass for a wave that
+      // has none at all: their fragments are loaded but never used, and the loads stay inside the packed array)
+      const int b = a.blkBegin + (npairs > 0 ? b0 + (i < npairs ? 4 * i : 0) : 0);
 #pragma unroll
       for (int m = 0; m < KS / 2; m++) {
         const vec2 cv = *as_global(reinterpret_cast<const vec2 *>(pk + (int64_t)(4 * m) * a.nVec8 + 8 * b));

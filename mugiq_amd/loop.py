@@ -40,7 +40,7 @@ class _CLoopPhase(ctypes.Structure):
 
 PHASE_NAMES = ["ultra_local", "entry_fused", "entry_reflected", "entry_stepwise", "momentum_projection", "halo_transfer",
                "entry_interior", "entry_boundary", "prolongation", "halo_prepare", "halo_wait", "momentum_copy",
-               "momentum_reduce", "total_wall"]                           # MUGIQ_HIP_PHASE_* (include/mugiq_hip.h)
+               "momentum_reduce", "total_wall", "scratch_alloc"]                           # MUGIQ_HIP_PHASE_* (include/mugiq_hip.h)
 
 
 @dataclass

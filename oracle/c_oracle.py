@@ -23,7 +23,19 @@ def load():
             f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                           ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                           ctypes.c_int64, ctypes.c_int64, ctypes.c_int]
+        _lib.oracle_first_touch_copy.restype = None
+        _lib.oracle_first_touch_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int]
     return _lib
+
+
+def first_touch_copy(src, n_planes, S):
+    """A copy of the flat numpy array `src` ([2 parities][n_planes][S] items) whose pages are first written by the OpenMP
+    threads that will read them in loop_contract_native (same static partition of the site index)."""
+    lib = load()
+    assert src.flags["C_CONTIGUOUS"] and src.nbytes % (2 * n_planes * S) == 0
+    dst = np.empty_like(src)                     # freshly mapped, untouched
+    lib.oracle_first_touch_copy(dst.ctypes.data, src.ctypes.data, n_planes, S, src.nbytes // (2 * n_planes * S))
+    return dst
 
 
 def num_threads():

@@ -8,7 +8,8 @@
  * PARITY UNPINNED: the reference holds no golden vectors for this path; this file is
  * cross-checked against the numpy oracle and the analytic KATs in tests/.
  *
- * Build: make -C oracle   (gcc -O3 -fcx-limited-range -fopenmp)
+ * Build: make -C oracle   (gcc -O3 -march=native -fcx-limited-range -fopenmp; rebuilt on the box it runs on if the
+ * instruction set differs -- see oracle/c_oracle.py)
  */
 #include <complex.h>
 #include <stdint.h>
@@ -41,40 +42,84 @@ static inline int64_t spinor_index(int order, int parity, int64_t x_cb, int k, i
   return parity * parity_offset + ((k / 2) * stride + x_cb) * 2 + (k % 2);
 }
 
+/* One block of W consecutive sites x all eigenvectors.  Per site the arithmetic and its order are those of :98-120 (colour sum
+ * kc = 0..2 from zero, the four-term gamma sum in s2 order from zero, inv_sigma * trace, += into loopData per eigenvector);
+ * the W sites of a block are independent lanes (real / imaginary parts in separate arrays so that the compiler can use the
+ * host's vector units), and a block touches whole cache lines of every plane. */
+#define ORACLE_W 8
 #define DEFINE_CONTRACT(NAME, REAL, CPLX)                                                                        \
-  /* site-outer, eigenvector-inner; per site the arithmetic and its order are those of :98-120 */               \
+  __attribute__((target_clones("avx512f", "avx2", "default"))) static void NAME##_block(CPLX *loop, const CPLX *const *vL, const CPLX *const *vR, const double *sigma, int nVec, \
+                           int64_t tid0, int w, int volumeCB, int64_t stride, int64_t parity_offset, int order) {   \
+    const int64_t V = 2 * (int64_t)volumeCB;                                                                      \
+    REAL lr[12][ORACLE_W], li[12][ORACLE_W], rr[12][ORACLE_W], ri[12][ORACLE_W], gr[16][ORACLE_W], gi[16][ORACLE_W]; \
+    for (int n = 0; n < nVec; n++) {                                                                               \
+      const REAL inv_sigma = (REAL)(1.0 / (REAL)sigma[n]);                                                         \
+      for (int k = 0; k < 12; k++)                                                                                 \
+        for (int j = 0; j < w; j++) {                                                                              \
+          const int64_t tid = tid0 + j;                                                                            \
+          const int pty = tid >= volumeCB;                                                                         \
+          const int64_t i = spinor_index(order, pty, tid - (int64_t)pty * volumeCB, k, stride, parity_offset);     \
+          lr[k][j] = creal(vL[n][i]);                                                                              \
+          li[k][j] = cimag(vL[n][i]);                                                                              \
+          rr[k][j] = creal(vR[n][i]);                                                                              \
+          ri[k][j] = cimag(vR[n][i]);                                                                              \
+        }                                                                                                          \
+      for (int be = 0; be < 4; be++)                                                                               \
+        for (int al = 0; al < 4; al++) {                                                                           \
+          _Pragma("omp simd") for (int j = 0; j < ORACLE_W; j++) {                                                 \
+            REAL sr = 0, si = 0;                                                                                   \
+            for (int kc = 0; kc < 3; kc++) { /* s += conj(l) * r */                                                \
+              const REAL a = lr[be * 3 + kc][j], b = li[be * 3 + kc][j], c = rr[al * 3 + kc][j], d = ri[al * 3 + kc][j]; \
+              sr += a * c + b * d;                                                                                 \
+              si += a * d - b * c;                                                                                 \
+            }                                                                                                      \
+            gr[be * 4 + al][j] = sr;                                                                               \
+            gi[be * 4 + al][j] = si;                                                                               \
+          }                                                                                                        \
+        }                                                                                                          \
+      for (int iG = 0; iG < 16; iG++) {                                                                            \
+        REAL tr[ORACLE_W], ti[ORACLE_W];                                                                           \
+        for (int j = 0; j < ORACLE_W; j++) tr[j] = ti[j] = 0;                                                      \
+        for (int s2 = 0; s2 < 4; s2++) {                                                                           \
+          const int e = s2 * 4 + COLUMN_INDEX[iG][s2];                                                             \
+          const REAL a = (REAL)ROW_VALUE[iG][s2][0], b = (REAL)ROW_VALUE[iG][s2][1];                               \
+          _Pragma("omp simd") for (int j = 0; j < ORACLE_W; j++) { /* trace += g * resG */                         \
+            tr[j] += a * gr[e][j] - b * gi[e][j];                                                                  \
+            ti[j] += a * gi[e][j] + b * gr[e][j];                                                                  \
+          }                                                                                                        \
+        }                                                                                                          \
+        for (int j = 0; j < w; j++) loop[tid0 + j + V * iG] += inv_sigma * tr[j] + inv_sigma * ti[j] * I;          \
+      }                                                                                                            \
+    }                                                                                                              \
+  }                                                                                                                \
+  /* site-outer, eigenvector-inner */                                                                             \
   void NAME(CPLX *loop, const CPLX *const *vL, const CPLX *const *vR, const double *sigma, int nVec,             \
             int64_t site_begin, int64_t site_end, int volumeCB, int64_t stride, int64_t parity_offset, int order) { \
-    const int64_t V = 2 * (int64_t)volumeCB;                                                                      \
-    _Pragma("omp parallel for schedule(static)") for (int64_t tid = site_begin; tid < site_end; tid++) {          \
-      const int pty = tid >= volumeCB;                                                                             \
-      const int64_t x_cb = tid - (int64_t)pty * volumeCB;                                                          \
-      for (int n = 0; n < nVec; n++) {                                                                             \
-        const REAL inv_sigma = (REAL)(1.0 / (REAL)sigma[n]);                                                       \
-        CPLX l[12], r[12], resG[16];                                                                               \
-        for (int k = 0; k < 12; k++) {                                                                             \
-          const int64_t i = spinor_index(order, pty, x_cb, k, stride, parity_offset);                              \
-          l[k] = vL[n][i];                                                                                         \
-          r[k] = vR[n][i];                                                                                         \
-        }                                                                                                          \
-        for (int be = 0; be < 4; be++)                                                                             \
-          for (int al = 0; al < 4; al++) {                                                                         \
-            CPLX s = 0;                                                                                            \
-            for (int kc = 0; kc < 3; kc++) s += conj(l[be * 3 + kc]) * r[al * 3 + kc];                             \
-            resG[be * 4 + al] = s;                                                                                 \
-          }                                                                                                        \
-        for (int iG = 0; iG < 16; iG++) {                                                                          \
-          CPLX trace = 0;                                                                                          \
-          for (int s2 = 0; s2 < 4; s2++) {                                                                         \
-            const int s1 = COLUMN_INDEX[iG][s2];                                                                   \
-            const CPLX g = (REAL)ROW_VALUE[iG][s2][0] + (REAL)ROW_VALUE[iG][s2][1] * I;                            \
-            trace += g * resG[s2 * 4 + s1];                                                                        \
-          }                                                                                                        \
-          loop[tid + V * iG] += inv_sigma * trace;                                                                 \
-        }                                                                                                          \
-      }                                                                                                            \
+    const int64_t nblk = (site_end - site_begin + ORACLE_W - 1) / ORACLE_W;                                        \
+    _Pragma("omp parallel for schedule(static)") for (int64_t b = 0; b < nblk; b++) {                              \
+      const int64_t tid0 = site_begin + b * ORACLE_W;                                                              \
+      const int w = (int)(site_end - tid0 < ORACLE_W ? site_end - tid0 : ORACLE_W);                                \
+      NAME##_block(loop, vL, vR, sigma, nVec, tid0, w, volumeCB, stride, parity_offset, order);                    \
     }                                                                                                              \
   }
 
 DEFINE_CONTRACT(oracle_loop_contract_f64, double, double complex)
 DEFINE_CONTRACT(oracle_loop_contract_f32, float, float complex)
+
+/* First-touch placement for the cpu_baseline sample ([2 parities][nPlanes][S] items of itemBytes): copy src to dst with the
+ * SAME static partition of the site index tid = x + parity * S the contraction uses, so that every thread's share of every
+ * plane lands in memory next to the core that will read it.  dst must be freshly mapped (never written). */
+void oracle_first_touch_copy(void *dst, const void *src, int nPlanes, int64_t S, int itemBytes) {
+  const int64_t nblk = (S + ORACLE_W - 1) / ORACLE_W;
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < 2 * nblk; b++) {
+    const int64_t p = b >= nblk, x0 = (b - p * nblk) * ORACLE_W;
+    const int64_t w = S - x0 < ORACLE_W ? S - x0 : ORACLE_W;
+    for (int k = 0; k < nPlanes; k++) {
+      const int64_t off = ((p * nPlanes + k) * S + x0) * itemBytes;
+      char *d = (char *)dst + off;
+      const char *s_ = (const char *)src + off;
+      for (int64_t i = 0; i < w * itemBytes; i++) d[i] = s_[i];
+    }
+  }
+}

@@ -54,8 +54,9 @@ def _check_pos(orc, rank_coord, grid, G, l, cprm, pos_local, pos_global, tol):
         assert e < tol, ("dataPos", idata, e)
 
 
-def cpu_worker(rank, world, port, grid, G=(4, 4, 4, 8)):
-    """N>1 path on CPU: GridComm over gloo + oracle arithmetic == single-domain oracle."""
+def cpu_worker(rank, world, port, grid, G=(4, 4, 4, 8), force=(0, 0, 0, 0)):
+    """N>1 path on CPU: GridComm over gloo + oracle arithmetic == single-domain oracle.
+    force: axes of extent 1 on which the partitioned path is forced (the rank is its own neighbour)."""
     import torch
     from util import orc, momenta_p2_le, rel_err
     dist = _init(rank, world, port)
@@ -66,7 +67,7 @@ def cpu_worker(rank, world, port, grid, G=(4, 4, 4, 8)):
     ev_lex, U_lex, sg = _global_problem(G, 2, 99)
     cprm, pos_g, mom_g = _single_domain_reference(orc, G, ev_lex, U_lex, sg, disp, moms, FTSign)
 
-    comm = GridComm(grid)
+    comm = GridComm(grid, force_partitioned=force)
     assert comm.rank_of(comm.coord) == rank and comm.coords_of(rank) == comm.coord
     l = [G[d] // grid[d] for d in range(4)]
     commDim = [comm.comm_dim_partitioned(d) for d in range(4)]
@@ -109,8 +110,9 @@ def cpu_worker(rank, world, port, grid, G=(4, 4, 4, 8)):
     dist.destroy_process_group()
 
 
-def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8), seed=None):
-    """The C++ driver on every rank (all on cuda:0), halos and FT reduction through the comm callbacks."""
+def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8), seed=None, force=(0, 0, 0, 0)):
+    """The C++ driver on every rank (all on cuda:0), halos and FT reduction through the comm callbacks.
+    force: axes of extent 1 on which the partitioned path is forced (MugiqHipComm.partitioned; self-neighbour)."""
     import torch
     from util import orc, momenta_p2_le, rel_err
     dist = _init(rank, world, port)
@@ -140,7 +142,7 @@ def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8), 
     U_lex = U_lex.astype(cdt).astype(np.complex128)
     cprm, pos_g, mom_g = _single_domain_reference(orc, G, ev_lex, U_lex, sg, disp, moms, FTSign)
 
-    comm = hip.GridComm(grid, device="cuda:0")
+    comm = hip.GridComm(grid, device="cuda:0", force_partitioned=force)
     l = [G[d] // grid[d] for d in range(4)]
     brd = [2 * comm.comm_dim_partitioned(d) for d in range(4)]
     # Displace's setup: host QDP links of the LOCAL lattice -> extended device field, borders from the neighbours
@@ -255,5 +257,66 @@ def nccl_world1_worker(rank, world, port, loopback):
     # (the ultra-local loop has a phase of its own unless a displaced entry carried it along as a fourth slot)
     assert ("ultra_local" in kinds or "entry_fused" in kinds) and "momentum_projection" in kinds and kinds[-1] == "total_wall", kinds
     loop.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def forced_full_size_worker(rank, world, port, X, nev, force, backend):
+    """BASELINE.json configs[2]'s per-GPU lattice on ONE rank with the partitioned path forced on `force` axes (the rank is
+    its own neighbour): packed face layers, ghost-layer reads, interior / boundary tiles, halos of reflected slots and gauge
+    borders through sendrecv at the real size, against an independent path -- the unpartitioned run of the same job, which
+    wraps around inside the kernels.  The oracle is far too slow at this size; small lattices of the same construction are
+    checked against it by test_forced_partitioning_on_one_rank."""
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    import mugiq_amd as hip
+    from bench import make_evecs, make_gauge, momenta_p2_le, ENTRIES_CFG2
+    _, f = make_evecs(hip, X, nev, 8, 2, dev, seed=11)
+    sg = 0.01 + 0.002 * np.arange(nev)
+    moms = momenta_p2_le(2)
+    comm = hip.GridComm((1, 1, 1, 1), device=dev, force_partitioned=force)
+    g_plain = make_gauge(hip, X, 8, dev, 4321, None)            # written in place, no border: shifts wrap inside the kernels
+    g_part = make_gauge(hip, X, 8, dev, 4321, comm)             # host QDP links -> borders R = 2 through sendrecv (self)
+    assert list(g_part.R) == [2 * int(bool(x)) for x in force]
+
+    def run(gauge, cm, calc, entries, n):
+        prm = hip.MugiqLoopParam(gauge=gauge, calcType=calc, doMomProj=True, momMatrix=moms, Nmom=len(moms), FTSign=-1)
+        prm.set_displace_entry_string(entries)
+        loop = hip.Loop_Mugiq(prm, f[:n], sg[:n], cm).setProfiling()
+        loop.computeCoarseLoop()
+        pos, mom = loop.dataPos_d.clone(), np.array(loop.dataMom_global())
+        kinds = set(p["kind"] for p in loop.phases())
+        der = [loop.derivedFrom(i) for i in range(loop.nDispEntries)]
+        loop.close()
+        return pos, mom, kinds, der
+
+    ref_pos, ref_mom, _, ref_der = run(g_plain, None, hip.LOOP_CALC_TYPE_OPT_KERNEL, ENTRIES_CFG2, nev)
+    scale, mscale = float(ref_pos.abs().max()), float(np.abs(ref_mom).max())
+    for ahead in ("1", "0"):
+        os.environ["MUGIQ_HIP_HALO_AHEAD"] = ahead
+        pos, mom, kinds, der = run(g_part, comm, hip.LOOP_CALC_TYPE_OPT_KERNEL, ENTRIES_CFG2, nev)
+        assert der == ref_der
+        assert {"halo_transfer", "entry_interior", "entry_boundary"} <= kinds, kinds
+        e = float((pos - ref_pos).abs().max()) / scale
+        assert e < 1e-13, ("forced partition, position space, halo ahead " + ahead, e)
+        em = float(np.abs(mom - ref_mom).max()) / mscale
+        assert em < 1e-12, ("forced partition, momentum space", em)
+        del pos
+    os.environ.pop("MUGIQ_HIP_HALO_AHEAD", None)
+    # the reference's own sequence (BASIC: one face exchange per step and eigenvector) on a subset
+    sub = "+z:1,2;-t:1;+x:1"
+    b_pos, b_mom, _, _ = run(g_part, comm, hip.LOOP_CALC_TYPE_BASIC_KERNEL, sub, 2)
+    o_pos, o_mom, _, _ = run(g_plain, None, hip.LOOP_CALC_TYPE_OPT_KERNEL, sub, 2)
+    e = float((b_pos - o_pos).abs().max()) / float(o_pos.abs().max())
+    assert e < 1e-13, ("forced partition, BASIC", e)
+    assert float(np.abs(b_mom - o_mom).max()) / float(np.abs(o_mom).max()) < 1e-12
     dist.barrier()
     dist.destroy_process_group()

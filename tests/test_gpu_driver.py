@@ -593,6 +593,26 @@ def test_driver_random_shapes_both_fused_plans(hip, seed, monkeypatch, record_ma
         assert err < tol and err_mom < tol, (X, prec, order, nev, entry, pad, gpad, "basic", err, err_mom)
 
 
+@pytest.mark.parametrize("force,G,prec,order,calc,ahead", [((0, 0, 0, 1), (4, 4, 8, 8), 8, 2, 1, "1"), ((0, 0, 1, 1), (4, 4, 8, 8), 8, 2, 1, "1"),
+                                                           ((0, 0, 1, 1), (4, 4, 8, 8), 8, 2, 1, "0"), ((0, 0, 1, 1), (4, 4, 8, 8), 4, 4, 2, "1"),
+                                                           ((1, 1, 0, 0), (8, 8, 4, 4), 8, 4, 1, "1"), ((1, 1, 1, 1), (4, 4, 4, 4), 4, 2, 1, "1"),
+                                                           ((0, 0, 0, 1), (8, 4, 4, 4), 8, 2, 1, "1")])
+def test_forced_partitioning_on_one_rank(force, G, prec, order, calc, ahead, monkeypatch):
+    """MugiqHipComm.partitioned (QUDA's comm_dim_partitioned_set): ONE rank runs the partitioned code path on axes of extent 1
+    as its own neighbour -- extended gauge borders through sendrecv, packed multi-layer halos (posted ahead or not), interior /
+    boundary tiles, reflected slots with halo, BASIC's face per step, and (t extent 4) the step-by-step sequence for a length
+    past the local extent -- and must reproduce the single-domain oracle."""
+    monkeypatch.setenv("MUGIQ_HIP_HALO_AHEAD", ahead)
+    mp.spawn(mp_workers.gpu_worker, args=(1, free_port(), (1, 1, 1, 1), prec, order, calc, G, None, force), nprocs=1, join=True)
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_full_size_forced_partition_equals_unpartitioned(backend):
+    """configs[2] per-GPU lattice 48.48.24.24 with z and t forced-partitioned (its 1x1x2x4 grid seen from one rank): all 8
+    entries x lengths 1..3, OPT with halos posted ahead and not, BASIC on a subset == the unpartitioned run to 1e-13."""
+    mp.spawn(mp_workers.forced_full_size_worker, args=(1, free_port(), (48, 48, 24, 24), 4, (0, 0, 1, 1), backend), nprocs=1, join=True)
+
+
 def test_full_size_reflected_entries_agree_with_computed_ones(hip, monkeypatch):
     """BASELINE.json configs[2] per-GPU lattice (48.48.24.24), few eigenvectors: the OPT plan with reflected entries, without
     them, and with the streaming kernel give the same 25 loop slots (a size-independent property; the oracle is too

@@ -36,3 +36,10 @@ def test_four_rank_gloo_extent_four(grid, G):
 def test_eight_rank_gloo_baseline_grid():
     """BASELINE.json configs[2]'s process grid, 1 x 1 x 2 x 4 (z and t partitioned, t extent 4), on 8 gloo ranks."""
     mp.spawn(mp_workers.cpu_worker, args=(8, free_port(), (1, 1, 2, 4)), nprocs=8, join=True)
+
+
+@pytest.mark.parametrize("grid,world,force", [((1, 1, 1, 1), 1, (0, 0, 1, 1)), ((1, 1, 1, 1), 1, (1, 1, 0, 0)), ((1, 1, 1, 2), 2, (0, 0, 1, 0))])
+def test_forced_partitioning_self_neighbour(grid, world, force):
+    """comm_dim_partitioned forced on axes of extent 1 (QUDA's comm_dim_partitioned_set): ghost zones, face exchange and
+    gauge borders run with the rank as its own neighbour and must reproduce the single-domain result."""
+    mp.spawn(mp_workers.cpu_worker, args=(world, free_port(), grid, (4, 4, 4, 8), force), nprocs=world, join=True)
