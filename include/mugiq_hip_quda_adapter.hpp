@@ -1,8 +1,12 @@
 // mugiq_hip_quda_adapter.hpp -- the MuGiq/QUDA-side binding of libmugiq_hip.so.
 //
-// STATUS: this file is shipped source, NOT built or tested in this repository: it needs QUDA's headers (color_spinor_field.h,
+// STATUS: this file is shipped source, never LINKED or RUN in this repository: it needs QUDA's headers (color_spinor_field.h,
 // gauge_field.h, comm_quda.h, transfer.h, index_helper.cuh) and MuGiq's (mugiq.h, eigsolve_mugiq.h, mg_mugiq.h), none of
 // which exist in the build image (QUDA is not vendored by the reference and no version is pinned, CMakeLists.txt:112-114).
+// It does go through a compiler: tests/test_adapter_syntax.py runs it, both switches on, through `-fsyntax-only` against
+// declaration-only stand-ins for the QUDA / MPI / Eigsolve_Mugiq names it touches (tests/quda_stub/) and, where the reference
+// tree is mounted, against the reference's own include/mugiq.h + include/enum_mugiq.h -- that pins templates, signatures and
+// C-ABI calls, and nothing about layouts (see 5. below).
 // Everything QUDA-independent that it calls IS built and tested here (include/mugiq_hip_operators.hpp, tests/cpp/loop.cpp).
 // The QUDA accessors used below are those of QUDA develop, early-to-mid 2020 (the reference's vintage);
 // a maintainer on another QUDA version adjusts the few lines marked [QUDA-API].
