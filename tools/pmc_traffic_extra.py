@@ -4,7 +4,9 @@
 corrected as MI355X_MICROARCH.md (HBM section) prescribes for gfx950 (KiB units; FETCH_SIZE x 2 for 16-B-per-lane streams).
 bench.py attaches these figures to the roofline blocks of its extra legs when the library sources are unchanged.
 
-usage: pmc_traffic_extra.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+usage: pmc_traffic_extra.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [displaced-nev]
+(displaced-nev: the --displaced-nev of the profiled bench.py run, default 400; the figures of the displaced leg are attached only
+to a run with the same number of eigenvectors)
 """
 import collections
 import csv
@@ -51,7 +53,7 @@ if __name__ == "__main__":
         wv = w.get((name, grid), (0.0, 0))[0]
         kernels.append({"name": name, "grid": grid, "launches_averaged": n, "fetch_bytes_corrected_x2": 2.0 * fv * 1024.0,
                         "write_bytes": wv * 1024.0, "hbm_bytes_per_launch": 2.0 * fv * 1024.0 + wv * 1024.0})
-    json.dump({"library_fingerprint": library_fingerprint(),
+    json.dump({"library_fingerprint": library_fingerprint(), "displaced_nev": int(sys.argv[4]) if len(sys.argv) > 4 else 400,
                "correction": "gfx950: FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE x 2 for 16 B/lane coalesced streams (MI355X_MICROARCH.md, HBM)",
                "kernels": kernels}, open(sys.argv[3], "w"), indent=1)
     print("wrote %s (%d kernels, library %s)" % (sys.argv[3], len(kernels), library_fingerprint()))
