@@ -344,10 +344,12 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
         out["ultra_local"] = "carried by a displaced entry as a fourth slot of the tiled kernel (no pass of its own)"
     ms_r = phase_sum(ph, "entry_reflected")
     nref = sum(3 for d in best["derived"] if d >= 0)
-    if nref:
+    if nref and ms_r > 0:
         out["roofline"]["reflected_slots"] = roof("hbm", "reflect_kernel (%d slots)" % nref, ms_r, nref * V * 2 * 32 * B)
+    elif nref:
+        out["reflected_slots"] = "derived in momentum space on the gathered array (host, %.3f ms); never formed in position space" % phase_sum(ph, "momentum_reflect")
     ms_m = phase_sum(ph, "momentum_projection")
-    nData = 16 * best["nLoop"]
+    nData = 16 * (best["nLoop"] - (nref if nref and ms_r == 0 else 0))     # slots that went through the reorder + Fourier kernels
     npx = len(set(m[0] for m in moms))
     out["roofline"]["momentum_projection"] = roof("hbm", "eo_dft_x (reorder + x sum) + partial_dft_kernel (y, z)", ms_m,
                                                   V * nData * 2 * B * (1 + npx / X[0]),

@@ -291,6 +291,26 @@ int mugiq_hip_convert_and_project(void *dataMom_d, const void *dataPos_d, int nD
                                   int FTSign, const int localL[4], const int totalL[4], const int commCoord[4], int precision,
                                   void *workspace_d, size_t workspace_bytes, void *stream);
 
+/* The same for a SUBSET of the loop slots (new): only the slots slots_h[0 .. nSlots) of dataPos_d ([nLoop][16][V]) are read,
+ * and only their rows t + locT*(ig + 16*slot) of dataMom_d (the full [locT*16*nLoop x Nmom] array) are written; the rows of the
+ * other slots keep what they held.  The OPT plan uses it to leave reflected slots out of the projection (see
+ * mugiq_hip_reflect_momentum_space). */
+int mugiq_hip_convert_and_project_slots(void *dataMom_d, const void *dataPos_d, int nLoop, const int *slots_h, int nSlots,
+                                        const int *momMatrix_h, int Nmom, int FTSign, const int localL[4], const int totalL[4],
+                                        const int commCoord[4], int precision, void *workspace_d, size_t workspace_bytes, void *stream);
+
+/* Reflected displacement entries in momentum space (new; host arrays only, no device work).  With L^-_k(x) = eta conj(L^+_k(x - k mu))
+ * (mugiq_hip_reflect_displaced_loop), the Fourier transform of the derived slot follows from that of its source slot:
+ *   dst(p, ig, t) = eta(15-ig) exp(-+ i FTSign 2 pi p_mu k / totalL[mu]) conj( src(-p, ig, t) )      mu = x, y, z
+ *   dst(p, ig, t) = eta(15-ig) conj( src(-p, ig, t +- k) )   (t periodic over totT)                   mu = t
+ * upper signs for dstDispSign = "+" (derived from a "-" entry).  dataMom_bcast_h: the gathered array of
+ * performMomentumProjection (lib/loop_mugiq.cpp:415-424: per time-rank slabs of t + locT*ig + locT*16*iL + locT*16*nLoop*im);
+ * slot srcSlot must be complete, slot dstSlot is overwritten.  MUGIQ_HIP_ERROR_UNSUPPORTED if some momentum of the list has no
+ * partner -p in it. */
+int mugiq_hip_reflect_momentum_space(void *dataMom_bcast_h, int precision, int Nmom, const int *momMatrix_h, int FTSign,
+                                     const int totalL[4], int nLoop, int locT, int totT, int dstSlot, int srcSlot, int dispDir,
+                                     int dstDispSign, int length);
+
 /* ==== f2: MG coarse path -- Loop_Mugiq::prolongateEvec (lib/loop_mugiq.cpp:277-319) = QUDA Transfer::P ============== */
 
 /* A coarse-grid colour-spinor in QUDA's FLOAT2 order (what Eigsolve_Mugiq hands over when computeCoarse is set,
@@ -492,6 +512,7 @@ int mugiq_hip_loop_ultra_local_carrier(const MugiqHipLoop *loop);
 #define MUGIQ_HIP_PHASE_MOMENTUM_COPY 11       /* dataMom_d -> pinned host */
 #define MUGIQ_HIP_PHASE_MOMENTUM_REDUCE 12     /* host: reduce over space ranks, gather over time ranks, broadcast (wall time) */
 #define MUGIQ_HIP_PHASE_TOTAL_WALL 13          /* host wall time of the whole mugiq_hip_loop_compute call (always the last phase) */
+#define MUGIQ_HIP_PHASE_MOMENTUM_REFLECT 15     /* host: reflected entries derived on the gathered momentum-space array (wall time) */
 #define MUGIQ_HIP_PHASE_SCRATCH_ALLOC 14       /* host: hipMalloc of scratch / halo buffers the pool did not hold yet (wall time, bytes) */
 typedef struct MugiqHipLoopPhase_s {
   int kind;     /* MUGIQ_HIP_PHASE_* */
@@ -503,7 +524,12 @@ int mugiq_hip_loop_set_profiling(MugiqHipLoop *loop, int on);
 /* phases of the last compute, in issue order; returns their number (may exceed max_phases; out may be NULL to ask) */
 int mugiq_hip_loop_get_phases(const MugiqHipLoop *loop, MugiqHipLoopPhase *out, int max_phases);
 /* dataPos_d: [nLoop][16][V even-odd] complex, device.  dataPos (host) is copied on first request
- * (the reference copies it unconditionally at lib/loop_mugiq.cpp:512). */
+ * (the reference copies it unconditionally at lib/loop_mugiq.cpp:512).
+ * With momentum projection on, the OPT plan derives reflected displacement entries in MOMENTUM space
+ * (mugiq_hip_reflect_momentum_space) and leaves their position-space slots out of the compute; the first call of either accessor
+ * after such a compute produces them (mugiq_hip_reflect_displaced_loop), so what is returned is always complete.  On a process
+ * grid with a reflected entry along a partitioned direction that first call exchanges the slots' boundary layers through
+ * comm->sendrecv: every rank must make it.  MUGIQ_HIP_REFLECT_MOM=0 keeps everything in position space inside the compute. */
 const void *mugiq_hip_loop_data_pos_d(const MugiqHipLoop *loop);
 const void *mugiq_hip_loop_data_pos_h(MugiqHipLoop *loop);
 /* dataMom_bcast (host): per time-rank slabs of t + locT*ig + locT*16*iL + locT*16*nLoop*im, concatenated in

@@ -16,7 +16,7 @@ from .operators import (  # noqa: E402
 )
 from ._lib import MugiqHipError, LIB_PATH  # noqa: E402
 from .loop import (  # noqa: E402
-    MugiqLoopParam, Loop_Mugiq, parseDisplaceEntryString, parseDisplacement, read_momenta_file, writeLoopsHDF5_Mom,
+    MugiqLoopParam, Loop_Mugiq, parseDisplaceEntryString, parseDisplacement, read_momenta_file, writeLoopsHDF5_Mom, reflectMomentumSpace,
     LOOP_CALC_TYPE_BLAS, LOOP_CALC_TYPE_OPT_KERNEL, LOOP_CALC_TYPE_BASIC_KERNEL,
 )
 from .comm import GridComm  # noqa: E402

@@ -104,6 +104,10 @@ SIGNATURES = {
                                                                ctypes.c_int, ctypes.c_int, _VP, ctypes.c_size_t, _VP]),
     "mugiq_hip_convert_and_project": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, _I4, ctypes.c_int, ctypes.c_int, _I4, _I4, _I4,
                                                      ctypes.c_int, _VP, ctypes.c_size_t, _VP]),
+    "mugiq_hip_convert_and_project_slots": (ctypes.c_int, [_VP, _VP, ctypes.c_int, _I4, ctypes.c_int, _I4, ctypes.c_int, ctypes.c_int, _I4, _I4, _I4,
+                                                           ctypes.c_int, _VP, ctypes.c_size_t, _VP]),
+    "mugiq_hip_reflect_momentum_space": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, _I4, ctypes.c_int, _I4, ctypes.c_int, ctypes.c_int,
+                                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "mugiq_hip_pack_face_layers": (ctypes.c_int, [_VP, _SP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP]),
     "mugiq_hip_reflect_displaced_loop": (ctypes.c_int, [_VP, _VP, _VP, _I4, ctypes.c_int, ctypes.c_int, ctypes.c_int, _I4, ctypes.c_int, _VP]),
     "mugiq_hip_pack_loop_layers": (ctypes.c_int, [_VP, _VP, _I4, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP]),

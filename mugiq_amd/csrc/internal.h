@@ -36,6 +36,10 @@ int upload_table(void **dev, const void *host, size_t bytes, hipStream_t stream)
 int release_stream_scratch(hipStream_t stream);
 size_t eo_dft_x_lds_bytes(int precision, const int localL[4], int nPx, int *redOffsetElems);  // momproj.hip
 int fill_identity_links(const MugiqHipSpinorField *f, hipStream_t stream);  // displace.hip
+}  // namespace mugiq
+#include <vector>
+namespace mugiq {
+bool momenta_negation_table(const int *mom, int Nmom, std::vector<int> &neg);  // reflect_mom.cpp
 
 // ---- address spaces ---------------------------------------------------------------------------------------------
 // Pointers fetched from a device-side table (eigenvector bodies) have no known address space, so hipcc emits

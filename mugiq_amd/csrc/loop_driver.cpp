@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "internal.h"
@@ -77,6 +78,9 @@ struct MugiqHipLoop_s {
   // mugiq_hip_displaced_loop_contraction_fused_carry); ultraCarried says whether an entry of this compute has produced it
   bool carryUltra = false, ultraCarried = false;
   int ultraCarrier = -1;  // the entry that took it along in the last compute, or -1
+  // OPT plan, momentum-space output: reflected entries are derived on the gathered momentum-space array (csrc/reflect_mom.cpp)
+  // and exist in position space only once somebody asks for dataPos (posReflectPending: not materialised yet)
+  bool momReflect = false, posReflectPending = false;
   // ---- MG coarse path (eigsolve->computeCoarse): coarse eigenvectors + one Transfer level (lib/loop_mugiq.cpp:277-319,482)
   bool coarseMode = false;
   std::vector<MugiqHipCoarseField> coarseVecs;
@@ -597,10 +601,37 @@ static void destroy_pool(MugiqHipLoop *lp) {
   lp->scratch.clear();
 }
 
+// the position-space slots of the reflected entries a compute left out (momentum-space reflection): produced on first request
+static int materialise_reflected(MugiqHipLoop *lp) {
+  if (!lp->posReflectPending) return MUGIQ_HIP_SUCCESS;
+  const size_t cb = lp->loopBytes();
+  int st = MUGIQ_HIP_SUCCESS;
+  for (int id = 0; id < lp->nDispEntries && !st; id++) {
+    if (lp->derivedFrom[id] < 0) continue;
+    void *slot0 = static_cast<char *>(lp->dataPos_d) + (size_t)lp->nElemPosLocPerLoop * lp->nLoopOffset[id] * cb;
+    st = entry_reflected(lp, id, lp->derivedFrom[id], slot0);
+    free_scratch(lp);
+  }
+  hipError_t e = hipStreamSynchronize(lp->stream);
+  if (!st && e != hipSuccess) st = set_error(MUGIQ_HIP_ERROR_HIP, "dataPos: %s", hipGetErrorString(e));
+  if (!st) lp->posReflectPending = false;
+  return st;
+}
+
+// can the fused reorder + x step take this lattice?  (else: reorder, then the three separable steps)
+static bool fused_projection_applies(const MugiqHipLoop *lp) {
+  std::vector<int> px;
+  for (int n = 0; n < lp->Nmom; n++)
+    if (std::find(px.begin(), px.end(), lp->momMatrix[3 * n]) == px.end()) px.push_back(lp->momMatrix[3 * n]);
+  const size_t tileBytes = eo_dft_x_lds_bytes(lp->loopPrecision, lp->localL, (int)px.size(), nullptr);
+  return tileBytes <= 64 * 1024 && lp->localL[2] <= 65535 && lp->nData <= 65535;
+}
+
 // Loop_Mugiq::performMomentumProjection  lib/loop_mugiq.cpp:322-434
 static int momentum_projection(MugiqHipLoop *lp) {
   if (lp->momProjDone) return set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "performMomentumProjection: Not supposed to be called more than once!!");
   int st;
+  std::vector<int> activeSlots;  // momentum-space reflection: the loop slots that go through the projection
   const int phDev = phase_begin(lp, MUGIQ_HIP_PHASE_MOMENTUM_PROJECTION, -1, lp->stream);
   if (lp->calcType == MUGIQ_HIP_LOOP_CALC_TYPE_BASIC_KERNEL) {
     // the reference's sequence: reorder (:343-344), then one dense product with the phase matrix of createPhaseMatrixGPU (:363-378)
@@ -616,11 +647,19 @@ static int momentum_projection(MugiqHipLoop *lp) {
     int coord[4] = {0, 0, 0, 0};
     if (lp->haveComm)
       for (int d = 0; d < 4; d++) coord[d] = lp->comm.coord[d];
-    std::vector<int> px;  // distinct p_x: the phase rows of the x step
-    for (int n = 0; n < lp->Nmom; n++)
-      if (std::find(px.begin(), px.end(), lp->momMatrix[3 * n]) == px.end()) px.push_back(lp->momMatrix[3 * n]);
-    const size_t tileBytes = eo_dft_x_lds_bytes(lp->loopPrecision, lp->localL, (int)px.size(), nullptr);
-    if (tileBytes <= 64 * 1024 && lp->localL[2] <= 65535 && lp->nData <= 65535) {
+    if (lp->momReflect) {
+      // only the slots computed from the eigenvectors are transformed; the reflected ones follow on the gathered array below
+      for (int id = -1; id < lp->nDispEntries; id++) {
+        if (id >= 0 && lp->derivedFrom[id] >= 0) continue;
+        const int first = id < 0 ? 0 : lp->nLoopOffset[id], cnt = id < 0 ? 1 : lp->nLoopPerEntry[id];
+        for (int i = 0; i < cnt; i++) activeSlots.push_back(first + i);
+      }
+      // (the rows of the reflected slots in dataMom_d stay zero -- allocated zeroed, never written -- until they are derived)
+      if ((st = mugiq_hip_convert_and_project_slots(lp->dataMom_d, lp->dataPos_d, lp->nLoop, activeSlots.data(), (int)activeSlots.size(),
+                                                    lp->momMatrix.data(), lp->Nmom, lp->FTSign, lp->localL, lp->totalL, coord,
+                                                    lp->loopPrecision, nullptr, 0, lp->stream)))
+        return st;
+    } else if (fused_projection_applies(lp)) {
       if ((st = mugiq_hip_convert_and_project(lp->dataMom_d, lp->dataPos_d, lp->nData, lp->nLoop, lp->momMatrix.data(), lp->Nmom, lp->FTSign,
                                               lp->localL, lp->totalL, coord, lp->loopPrecision, nullptr, 0, lp->stream)))
         return st;
@@ -653,6 +692,41 @@ static int momentum_projection(MugiqHipLoop *lp) {
   }  // (one process: dataMom and dataMom_bcast alias dataMom_h)
   phase_host(lp, MUGIQ_HIP_PHASE_MOMENTUM_REDUCE, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tRed0).count(),
              2.0 * (double)lp->nElemMomLoc * lp->loopPrecision);
+  if (lp->momReflect) {
+    // the reflected entries, on the gathered array (every rank holds it after the broadcast): csrc/reflect_mom.cpp
+    const auto tRef0 = std::chrono::steady_clock::now();
+    struct Task {
+      int dst, src, dir, sign, k;
+    };
+    std::vector<Task> tasks;
+    for (int id = 0; id < lp->nDispEntries; id++) {
+      const int jd = lp->derivedFrom[id];
+      if (jd < 0) continue;
+      for (int k = lp->dispStart[id]; k <= lp->dispStop[id]; k++)
+        tasks.push_back({lp->nLoopOffset[id] + k - lp->dispStart[id], lp->nLoopOffset[jd] + k - lp->dispStart[jd], lp->dispDir[id], lp->dispSign[id], k});
+    }
+    // the slots are independent (distinct destinations, sources only read): one host thread per slot, up to the cores there are
+    // (a slot is ~50k complex numbers scattered over the 20 MB array: 0.2 ms each when taken one after the other)
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nThreads = std::min<size_t>(std::min<size_t>(tasks.size(), hw), 16);
+    std::vector<int> status(nThreads, 0);
+    std::vector<std::string> message(nThreads);
+    auto work = [&](size_t w) {
+      for (size_t i = w; i < tasks.size() && !status[w]; i += nThreads) {
+        const Task &t = tasks[i];
+        status[w] = mugiq_hip_reflect_momentum_space(lp->dataMom_bcast, lp->loopPrecision, lp->Nmom, lp->momMatrix.data(), lp->FTSign, lp->totalL,
+                                                     lp->nLoop, lp->locT, lp->totT, t.dst, t.src, t.dir, t.sign, t.k);
+        if (status[w]) message[w] = mugiq_hip_last_error();  // (the error text is per thread)
+      }
+    };
+    std::vector<std::thread> pool;
+    for (size_t w = 1; w < nThreads; w++) pool.emplace_back(work, w);
+    if (nThreads) work(0);
+    for (auto &th : pool) th.join();
+    for (size_t w = 0; w < nThreads; w++)
+      if (status[w]) return set_error(status[w], "%s", message[w].c_str());
+    phase_host(lp, MUGIQ_HIP_PHASE_MOMENTUM_REFLECT, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tRef0).count());
+  }
   lp->momProjDone = true;
   return MUGIQ_HIP_SUCCESS;
 }
@@ -1026,6 +1100,18 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
       lp->halo[id].posted = false;
       any = any || ahead[id];
     }
+    // momentum-space output only needs the reflected entries in momentum space (csrc/reflect_mom.cpp): when the momentum list
+    // holds -p for every p they are left out of position space, of the reorder and of the Fourier kernels, and derived on the
+    // gathered array; dataPos materialises them on first request (MUGIQ_HIP_REFLECT_MOM=0: always in position space)
+    lp->momReflect = false;
+    if (lp->doMomProj && !lp->momProjDone) {
+      bool anyDerived = false;
+      for (int id = 0; id < lp->nDispEntries; id++) anyDerived = anyDerived || lp->derivedFrom[id] >= 0;
+      std::vector<int> neg;
+      bool on = true;
+      if (const char *e = getenv("MUGIQ_HIP_REFLECT_MOM")) on = atoi(e) != 0;
+      lp->momReflect = on && anyDerived && fused_projection_applies(lp) && momenta_negation_table(lp->momMatrix.data(), lp->Nmom, neg);
+    }
     const bool grouped = lp->haveComm && lp->comm.group_begin && lp->comm.group_end;
     if (any) {
       if ((st = ensure_comm_stream(lp))) return st;
@@ -1066,8 +1152,13 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
       order.push_back(-1);
     }
   }
+  lp->posReflectPending = false;
   for (int id : order) {
     if (id == -1 && !basic && lp->carryUltra && lp->ultraCarried) continue;  // produced by a displaced entry's pass
+    if (id >= 0 && !basic && lp->momReflect && lp->derivedFrom[id] >= 0) {   // derived in momentum space; position space on request
+      lp->posReflectPending = true;
+      continue;
+    }
     long long bufOffset;
     size_t bufByteSize;
     if (id != -1) {  // :465-474
@@ -1205,7 +1296,11 @@ int mugiq_hip_loop_entry_derived_from(const MugiqHipLoop *lp, int id) {
   return lp->derivedFrom[id];
 }
 
-const void *mugiq_hip_loop_data_pos_d(const MugiqHipLoop *lp) { return lp ? lp->dataPos_d : nullptr; }
+const void *mugiq_hip_loop_data_pos_d(const MugiqHipLoop *lp) {
+  if (!lp) return nullptr;
+  if (materialise_reflected(const_cast<MugiqHipLoop *>(lp))) return nullptr;  // (see mugiq_hip.h: slots left out by the last compute)
+  return lp->dataPos_d;
+}
 
 const void *mugiq_hip_loop_data_pos_h(MugiqHipLoop *lp) {
   if (!lp) return nullptr;
@@ -1218,6 +1313,7 @@ const void *mugiq_hip_loop_data_pos_h(MugiqHipLoop *lp) {
     }
   }
   if (!lp->dataPos) return nullptr;
+  if (materialise_reflected(lp)) return nullptr;
   if (!lp->dataPosCopied) {
     if (hipMemcpy(lp->dataPos, lp->dataPos_d, bytes, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;  // :512
     lp->dataPosCopied = true;

@@ -157,6 +157,10 @@ template <typename F> struct DftStepArgs {
   const int *groupSrc, *groupFirst, *groupCount;  // per group: source index in `innerIn`, first output, #outputs (<= kDftJT)
   const int *outRow, *outPos;                     // per output: phase row, position in the out array
   int M, Lsum, innerIn, nOut;
+  // last step of a projection over a SUBSET of the loop slots: row m = r + rowsPerSlot * c of the compact arrays goes to row
+  // r + rowsPerSlot * rowSlot[c] of an output with Mout rows per momentum (the full [locT*16*nLoop] layout); NULL: m itself
+  const int *rowSlot;
+  int rowsPerSlot, Mout;
 };
 
 template <typename F> __global__ __launch_bounds__(256) void partial_dft_kernel(DftStepArgs<F> a) {
@@ -184,9 +188,11 @@ template <typename F> __global__ __launch_bounds__(256) void partial_dft_kernel(
 #pragma unroll
     for (int j = 0; j < kDftJT; j++) cmadd(acc[j], v, phs[j * a.Lsum + sI]);
   }
+  const int c = a.rowSlot ? m / a.rowsPerSlot : 0;
+  const int mo = a.rowSlot ? m - c * a.rowsPerSlot + a.rowsPerSlot * a.rowSlot[c] : m;
 #pragma unroll
   for (int j = 0; j < kDftJT; j++)
-    if (j < cnt) a.out[((int64_t)o * a.nOut + a.outPos[first + j]) * a.M + m] = acc[j];
+    if (j < cnt) a.out[((int64_t)o * a.nOut + a.outPos[first + j]) * a.Mout + mo] = acc[j];
 }
 
 // Step x taken straight from the even-odd position-space buffer: the reorder of convertIdxOrder_mapGamma
@@ -205,7 +211,17 @@ template <typename F> struct EoDftArgs {
   int volumeCB, nPx, nPxPad, M;
   int tilesPerWg;      // pipelined kernel: consecutive y pairs per workgroup
   int redOffset;       // complex elements from the tile to the partial-sum area (0: the tile itself, single pass)
+  const int *slotMap;  // NULL: every loop slot; else compact slot c of the output <- slot slotMap[c] of dataPos (a subset of the slots)
 };
+
+// blockIdx.z = 16 * (compact slot) + ig of the OUTPUT: which channel of dataPos it is read from, and which row block it feeds
+template <typename F> __device__ inline void eo_dft_channels(const EoDftArgs<F> &a, int &ig, int &idataFrom, int &idataTo) {
+  const int ia = blockIdx.z, slotC = ia >> 4;
+  ig = ia & 15;
+  const int slotFrom = a.slotMap ? as_constant(a.slotMap)[slotC] : slotC;
+  idataFrom = slotFrom * 16 + ig;
+  idataTo = (15 - ig) + 16 * slotC;  // gammaMap->index[ig] + N_GAMMA_*iL   :89
+}
 
 // Measured on MI355X (48.48.24.24 fp64, 25 slots, 7 distinct p_x): the first version of this kernel let lane <-> (y, p_x, t)
 // read a data element AND a phase from LDS for every complex multiply-add -- 32 LDS bytes per 4 FMAs, four times what the
@@ -340,9 +356,9 @@ template <typename F> struct EoStager {
 template <typename F> __global__ __launch_bounds__(256) void eo_dft_x_pipelined_kernel(EoDftArgs<F> a) {
   extern __shared__ __align__(16) unsigned char smem[];
   Cplx<F> *tile = reinterpret_cast<Cplx<F> *>(smem);
-  const int z = blockIdx.y, idataFrom = blockIdx.z;
-  const int ig = idataFrom & 15;
-  const int idataTo = (15 - ig) + (idataFrom - ig);  // gammaMap->index[ig] + N_GAMMA_*iL   :89
+  const int z = blockIdx.y;
+  int ig, idataFrom, idataTo;
+  eo_dft_channels(a, ig, idataFrom, idataTo);
   const F sign = (F)kGammaMapSign[ig];               // gammaMap->sign[ig]                    :93
   const Cplx<F> *src = a.in + (int64_t)idataFrom * 2 * a.volumeCB;
   EoStager<F> st;
@@ -375,9 +391,9 @@ template <int NKS, int MB> __global__ __launch_bounds__(256) void eo_dft_x_mfma_
   extern __shared__ __align__(16) unsigned char smem[];
   Cplx<double> *tile = reinterpret_cast<Cplx<double> *>(smem);
   const int Lx = a.X[0], Ly = a.X[1], Lt = a.X[3], ld = Lx + 1;
-  const int z = blockIdx.y, idataFrom = blockIdx.z;
-  const int ig = idataFrom & 15;
-  const int idataTo = (15 - ig) + (idataFrom - ig);
+  const int z = blockIdx.y;
+  int ig, idataFrom, idataTo;
+  eo_dft_channels(a, ig, idataFrom, idataTo);
   const double sign = (double)kGammaMapSign[ig];
   const Cplx<double> *src = a.in + (int64_t)idataFrom * 2 * a.volumeCB;
   EoStager<double> st;
@@ -451,9 +467,9 @@ template <typename F> __global__ __launch_bounds__(256) void eo_dft_x_kernel(EoD
   extern __shared__ __align__(16) unsigned char smem[];
   const int Lx = a.X[0], Ly = a.X[1], Lz = a.X[2], Lt = a.X[3], ld = Lx + 1;  // padded rows: lanes walk the rows at a fixed x
   Cplx<F> *tile = reinterpret_cast<Cplx<F> *>(smem);                         // [kEoYG * Lt rows][Lx + 1]; later the partial sums
-  const int y0 = blockIdx.x * kEoYG, z = blockIdx.y, idataFrom = blockIdx.z;
-  const int ig = idataFrom & 15;
-  const int idataTo = (15 - ig) + (idataFrom - ig);  // gammaMap->index[ig] + N_GAMMA_*iL   :89
+  const int y0 = blockIdx.x * kEoYG, z = blockIdx.y;
+  int ig, idataFrom, idataTo;
+  eo_dft_channels(a, ig, idataFrom, idataTo);
   const F sign = (F)kGammaMapSign[ig];               // gammaMap->sign[ig]                    :93
   const Cplx<F> *src = a.in + (int64_t)idataFrom * 2 * a.volumeCB;
   // per (t, parity): the kEoYG * Lx/2 checkerboard entries of rows y0, y0+1 are contiguous ("run"); a wave fetches 64-entry
@@ -601,7 +617,8 @@ static size_t separable_workspace_elems(const SeparablePlan &P, const int localL
 
 template <typename F>
 static int launch_separable(void *C, const void *A, const void *dataPosEO, int nData, const int *mom, int Nmom, int FTSign,
-                            const int localL[4], const int totalL[4], const int commCoord[4], int M, void *ws, hipStream_t stream) {
+                            const int localL[4], const int totalL[4], const int commCoord[4], int M, void *ws, hipStream_t stream,
+                            const int *slotMap_h = nullptr, int nLoopOut = 0) {
   SeparablePlan P;
   build_plan(mom, Nmom, P);
   // one table: [phases x | phases y | phases z | int tables of the three steps]
@@ -629,6 +646,8 @@ static int launch_separable(void *C, const void *A, const void *dataPosEO, int n
       ints.insert(ints.end(), v[t]->begin(), v[t]->end());
     }
   }
+  const size_t slotOff = ints.size();
+  if (slotMap_h) ints.insert(ints.end(), slotMap_h, slotMap_h + nData / 16);
   const size_t phBytes = (ph.size() * sizeof(Cplx<F>) + 255) / 256 * 256;
   std::vector<unsigned char> host(phBytes + ints.size() * sizeof(int));
   memcpy(host.data(), ph.data(), ph.size() * sizeof(Cplx<F>));
@@ -663,6 +682,7 @@ static int launch_separable(void *C, const void *A, const void *dataPosEO, int n
     e.volumeCB = (int)(vol / 2);
     e.nPx = (int)P.px.size();
     e.M = M;
+    e.slotMap = slotMap_h ? int_d + slotOff : nullptr;
     const int run = kEoYG * localL[0] / 2, tiles = localL[1] / kEoYG;
     const bool pipelined = run <= 64 && (2 * localL[3] + 64 / run - 1) / (64 / run) <= 4 * kEoLd;
     // the sums on the matrix pipe where it applies (fp64; one pass: <= 64 rows, <= 8 distinct p_x; Lx = 24, 32, 48 or 64):
@@ -714,6 +734,13 @@ static int launch_separable(void *C, const void *A, const void *dataPosEO, int n
     a.Lsum = Lsum[st];
     a.innerIn = innerIn[st];
     a.nOut = P.nOut[st];
+    a.rowSlot = nullptr;
+    a.rowsPerSlot = 16 * localL[3];
+    a.Mout = M;
+    if (st == 2 && slotMap_h) {  // the subset's rows land in the full layout
+      a.rowSlot = int_d + slotOff;
+      a.Mout = a.rowsPerSlot * nLoopOut;
+    }
     const dim3 grid((M + 255) / 256, (unsigned)P.gSrc[st].size(), outer[st]);
     const size_t shmem = sizeof(Cplx<F>) * kDftJT * (size_t)Lsum[st];
     MUGIQ_REQUIRE(shmem <= 64 * 1024 && grid.y <= 65535 && grid.z <= 65535, "performMomentumProjection: lattice / momentum list too large for the separable plan");
@@ -814,6 +841,34 @@ int mugiq_hip_convert_and_project(void *dataMom_d, const void *dataPos_d, int nD
   if (precision == 8)
     return launch_separable<double>(dataMom_d, nullptr, dataPos_d, nData, momMatrix_h, Nmom, FTSign, localL, totalL, commCoord, locT * nData, ws, s);
   return launch_separable<float>(dataMom_d, nullptr, dataPos_d, nData, momMatrix_h, Nmom, FTSign, localL, totalL, commCoord, locT * nData, ws, s);
+}
+
+int mugiq_hip_convert_and_project_slots(void *dataMom_d, const void *dataPos_d, int nLoop, const int *slots_h, int nSlots,
+                                        const int *momMatrix_h, int Nmom, int FTSign, const int localL[4], const int totalL[4],
+                                        const int commCoord[4], int precision, void *workspace_d, size_t workspace_bytes, void *stream) {
+  const char *who = "performMomentumProjection";
+  MUGIQ_REQUIRE(dataMom_d && dataPos_d && slots_h && momMatrix_h && localL && totalL, "%s: NULL argument", who);
+  MUGIQ_REQUIRE(nLoop >= 1 && nSlots >= 1 && nSlots <= nLoop, "%s: nSlots = %d of nLoop = %d", who, nSlots, nLoop);
+  MUGIQ_REQUIRE(precision == 4 || precision == 8, "%s: Precision not supported!", who);
+  MUGIQ_REQUIRE(Nmom >= 1 && (FTSign == 1 || FTSign == -1), "%s: Nmom = %d, FTSign = %d", who, Nmom, FTSign);
+  long long vol = 1;
+  for (int d = 0; d < 4; d++) {
+    MUGIQ_REQUIRE(localL[d] > 0 && (localL[d] & 1) == 0 && totalL[d] > 0, "%s: localL[%d] = %d must be positive and even", who, d, localL[d]);
+    vol *= localL[d];
+  }
+  const int nData = 16 * nSlots, locT = localL[3];
+  for (int c = 0; c < nSlots; c++) MUGIQ_REQUIRE(slots_h[c] >= 0 && slots_h[c] < nLoop, "%s: slot %d is not in [0, %d)", who, slots_h[c], nLoop);
+  MUGIQ_REQUIRE(vol < (1LL << 31) && (long long)locT * 16 * nLoop < (1LL << 31), "%s: local volume overflows int", who);
+  const size_t need = mugiq_hip_momentum_projection_separable_workspace(momMatrix_h, Nmom, localL, locT, nData, precision);
+  void *ws = workspace_d;
+  if (ws == nullptr || workspace_bytes < need) {
+    int st = stream_workspace(&ws, need, static_cast<hipStream_t>(stream));
+    if (st) return st;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (precision == 8)
+    return launch_separable<double>(dataMom_d, nullptr, dataPos_d, nData, momMatrix_h, Nmom, FTSign, localL, totalL, commCoord, locT * nData, ws, s, slots_h, nLoop);
+  return launch_separable<float>(dataMom_d, nullptr, dataPos_d, nData, momMatrix_h, Nmom, FTSign, localL, totalL, commCoord, locT * nData, ws, s, slots_h, nLoop);
 }
 
 }  // extern "C"

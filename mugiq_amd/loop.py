@@ -40,7 +40,7 @@ class _CLoopPhase(ctypes.Structure):
 
 PHASE_NAMES = ["ultra_local", "entry_fused", "entry_reflected", "entry_stepwise", "momentum_projection", "halo_transfer",
                "entry_interior", "entry_boundary", "prolongation", "halo_prepare", "halo_wait", "momentum_copy",
-               "momentum_reduce", "total_wall", "scratch_alloc"]                           # MUGIQ_HIP_PHASE_* (include/mugiq_hip.h)
+               "momentum_reduce", "total_wall", "scratch_alloc", "momentum_reflect"]                           # MUGIQ_HIP_PHASE_* (include/mugiq_hip.h)
 
 
 @dataclass
@@ -113,6 +113,19 @@ def writeLoopsHDF5_Mom(filename, dataMom_bcast, momMatrix, disp_str, disp_start,
     _lib.check(_lib.load().mugiq_hip_write_loops_hdf5_mom(
         filename.encode(), a.ctypes.data_as(ctypes.c_void_p), prec, mom.size // 3, mom.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
         ne, ds, st, sp, int(locT), int(totT)))
+
+
+def reflectMomentumSpace(dataMom_bcast, momMatrix, FTSign, totalL, nLoop, locT, totT, dstSlot, srcSlot, dispDir, dstDispSign, length):
+    """mugiq_hip_reflect_momentum_space (host only): fill loop slot `dstSlot` of the gathered momentum-space array (flat complex
+    numpy, layout of lib/loop_mugiq.cpp:415-424) from its opposite-sign source slot, in place."""
+    a = dataMom_bcast
+    assert a.flags["C_CONTIGUOUS"] and a.dtype in (np.complex128, np.complex64)
+    mom = np.ascontiguousarray(np.asarray(momMatrix, dtype=np.int32).reshape(-1))
+    _lib.check(_lib.load().mugiq_hip_reflect_momentum_space(
+        a.ctypes.data_as(ctypes.c_void_p), 8 if a.dtype == np.complex128 else 4, mom.size // 3,
+        mom.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), int(FTSign), _lib.int4(totalL), int(nLoop), int(locT), int(totT),
+        int(dstSlot), int(srcSlot), int(dispDir), int(dstDispSign), int(length)))
+    return a
 
 
 class Loop_Mugiq:
@@ -261,6 +274,16 @@ class Loop_Mugiq:
         ptr = _lib.load().mugiq_hip_loop_data_pos_d(self._handle)
         nbytes = self.nElemPosLoc * 2 * self.loopPrecision
         return device_bytes(ptr, nbytes, self.device).view(torch.complex128 if self.loopPrecision == 8 else torch.complex64)
+
+    @property
+    def dataPos(self):
+        """host copy of the position-space loop buffer (dataPos of the reference, copied on request: lib/loop_mugiq.cpp:512)"""
+        ptr = _lib.load().mugiq_hip_loop_data_pos_h(self._handle)
+        if not ptr:
+            raise _lib.MugiqHipError("dataPos: %s" % (_lib.load().mugiq_hip_last_error() or b"?").decode())
+        ct = ctypes.c_double if self.loopPrecision == 8 else ctypes.c_float
+        a = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ct)), shape=(2 * self.nElemPosLoc,))
+        return a.view(np.complex128 if self.loopPrecision == 8 else np.complex64).copy()
 
     @property
     def dataMom_bcast(self):

@@ -692,3 +692,40 @@ def test_driver_reflects_opposite_sign_entries(hip, monkeypatch):
         assert [loop.derivedFrom(i) for i in range(8)] == expect[mode], mode     # "-x:1,3" is not covered by "+x:1,2"
         assert rel_err(loop.dataPos_d.cpu().numpy(), ref) < 1e-12, mode
         loop.close()
+
+
+@pytest.mark.parametrize("prec,order,FTSign", [(8, 2, -1), (8, 4, 1), (4, 4, -1)])
+def test_driver_reflects_in_momentum_space(hip, prec, order, FTSign, monkeypatch):
+    """OPT plan with momentum projection: reflected entries are derived on the momentum-space array (csrc/reflect_mom.cpp) and
+    left out of position space, of the reorder and of the Fourier kernels -- when the momentum list holds -p for every p.  The
+    momentum-space result equals the oracle's either way; dataPos is produced on request; a momentum list that is not closed
+    under p -> -p (and MUGIQ_HIP_REFLECT_MOM=0) keep the position-space reflection inside the compute."""
+    X = (4, 8, 4, 8)
+    nev = 3
+    ev, Uo, f, U = _setup(hip, X, nev, prec, order, 556)
+    sg = sigmas(nev)
+    entry = "+t:1,3;-t:1,3;-y:2,4;+y:3;+x:1,2;-x:1,3;-z:1;+z:1"
+    _, s, a, b = orc.parse_disp_entry_string(entry)
+    cprm = orc.LoopComputeParam(s, a, b)
+    pos = orc.compute_loop_position_space(ev, sg, cprm, Uo, X)
+    V, locV3 = int(np.prod(X)), X[0] * X[1] * X[2]
+    mp = orc.convert_idx_order_map_gamma(pos, cprm.nData, cprm.nLoop, 2, V // 2, X)
+    tol = 1e-12 if prec == 8 else 1e-5
+    closed = momenta_p2_le(3)
+    open_list = [m for m in closed if tuple(m) != (-1, -1, -1)]                 # (1, 1, 1) has lost its partner
+    for moms, env, in_mom_space in ((closed, None, True), (closed, "0", False), (open_list, None, False)):
+        if env is None:
+            monkeypatch.delenv("MUGIQ_HIP_REFLECT_MOM", raising=False)
+        else:
+            monkeypatch.setenv("MUGIQ_HIP_REFLECT_MOM", env)
+        ref = orc.momentum_projection_local(mp, orc.phase_matrix(moms, locV3, FTSign, X, X), X[3], cprm.nData, locV3, len(moms))
+        prm = hip.MugiqLoopParam(gauge=U, doMomProj=True, momMatrix=[list(m) for m in moms], Nmom=len(moms), FTSign=FTSign)
+        loop = hip.Loop_Mugiq(prm.set_displace_entry_string(entry), f, sg).setProfiling()
+        loop.computeCoarseLoop()
+        assert [loop.derivedFrom(i) for i in range(8)] == [-1, 0, -1, 2, -1, -1, -1, 6]
+        kinds = [p["kind"] for p in loop.phases()]
+        assert ("momentum_reflect" in kinds) == in_mom_space and ("entry_reflected" in kinds) == (not in_mom_space), kinds
+        assert rel_err(loop.dataMom_global(), ref.reshape(len(moms), cprm.nLoop, 16, X[3])) < tol
+        assert rel_err(loop.dataPos_d.cpu().numpy(), pos) < tol                 # materialised on request when it was left out
+        assert rel_err(loop.dataPos, pos) < tol
+        loop.close()

@@ -451,3 +451,50 @@ def test_minus_entry_is_shifted_conjugate_of_plus_entry():
                 m_lex = orc.eo_to_lex(minus[ig].reshape(2, V // 2), X)
                 shifted = np.roll(p_lex, k, axis=axis_of_dir[d])          # value at x - k mu
                 assert rel_err(m_lex, eta[ig] * shifted.conj()) < 1e-13, (name, k, ig)
+
+
+# ---- (11) the same identity in momentum space, after the G -> g5 G map of the reorder ----------------------------------------
+def reflect_momentum_space(mom_src, moms, FTSign, totalL, dirn, dst_sign_plus, k):
+    """Momentum-space data of the derived slot from the momentum-space data of its opposite-sign source slot:
+        dst[p, ig, t] = eta(15 - ig) * exp(-+ i FTSign 2 pi p_mu k / L_mu) * conj(src[-p, ig, t])            (mu spatial)
+        dst[p, ig, t] = eta(15 - ig) * conj(src[-p, ig, t +- k])                                              (mu = t)
+    upper signs for a derived "+" entry (source "-").  ig is the OUTPUT channel of convertIdxOrder_mapGamma (input channel 15 - ig,
+    real sign).  mom_src: [Nmom][16][totT].  The momentum list must hold -p for every p."""
+    eta = gamma_dagger_sign()
+    moms = [tuple(m) for m in moms]
+    out = np.empty_like(mom_src)
+    T = mom_src.shape[-1]
+    for im, p in enumerate(moms):
+        jm = moms.index(tuple(-c for c in p))
+        for ig in range(16):
+            v = np.conj(mom_src[jm, ig])
+            if dirn < 3:
+                sgn = -1.0 if dst_sign_plus else 1.0
+                out[im, ig] = eta[15 - ig] * np.exp(1j * sgn * FTSign * 2.0 * np.pi * p[dirn] * k / totalL[dirn]) * v
+            else:
+                out[im, ig] = eta[15 - ig] * np.roll(v, -k if dst_sign_plus else k)      # value at t + k | t - k
+    return out
+
+
+@pytest.mark.parametrize("FTSign", [-1, 1])
+def test_momentum_space_of_a_reflected_entry_follows_from_its_source(FTSign):
+    """Fourier transform of L^-_k = eta conj(L^+_k(x - k mu)): a phase, the momentum reversed, a conjugation -- so the engine can
+    skip the reflected slots in position space altogether when only momentum-space output is asked for."""
+    X = (4, 6, 4, 8)
+    rng = np.random.default_rng(77)
+    nev = 2
+    ev = [orc.lex_to_eo(random_spinor_lex(rng, X), X) for _ in range(nev)]
+    U = gauge_eo_single_domain(random_gauge_lex(rng, X), X)
+    V = int(np.prod(X))
+    moms = [m for m in momenta_p2_le(3)]
+    locV3 = X[0] * X[1] * X[2]
+    ph = orc.phase_matrix(moms, locV3, FTSign, X, X)
+    for d, name in enumerate("xyzt"):
+        cprm = orc.LoopComputeParam(["+" + name, "-" + name], [1, 1], [2, 2])
+        pos = orc.compute_loop_position_space(ev, sigmas(nev), cprm, U, X)
+        mp = orc.convert_idx_order_map_gamma(pos, cprm.nData, cprm.nLoop, 2, V // 2, X)
+        mom = orc.momentum_projection_local(mp, ph, X[3], cprm.nData, locV3, len(moms)).reshape(len(moms), cprm.nLoop, 16, X[3])
+        for k in (1, 2):
+            plus, minus = mom[:, 1 + (k - 1)], mom[:, 3 + (k - 1)]
+            assert rel_err(reflect_momentum_space(plus, moms, FTSign, X, d, False, k), minus) < 1e-13, (name, k, "minus from plus")
+            assert rel_err(reflect_momentum_space(minus, moms, FTSign, X, d, True, k), plus) < 1e-13, (name, k, "plus from minus")
