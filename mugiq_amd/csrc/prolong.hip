@@ -377,12 +377,19 @@ template <typename F, typename A> struct CoarseOuterArgs {
 constexpr int kCoEvecs = 8;   // eigenvectors staged per barrier
 constexpr int kCoMaxNC = 64;  // 2 * n_vec handled by the coarse path
 
+__device__ inline int xcd_contiguous_block(int blk, int nblk);
+
 // One workgroup per coarse site; the 256 threads tile C as 16 x 16 blocks of B x B entries (B = ceil(NC / 16)), so a
 // thread reads 2B components from LDS per B^2 complex multiply-adds.
+// A workgroup reads ONE 16-byte element of every (eigenvector, component) plane; the eight coarse sites of a 128-byte line are
+// eight workgroups.  Dealt round-robin over the 8 XCDs they pulled the line into eight L2s (PMC, round 2: 5.03 GB fetched for
+// 0.63 GB of coarse eigenvectors); XCD k now walks the k-th contiguous eighth of the sites, so the sharers of a line run side
+// by side on one XCD.
 template <typename F, typename A, int B> __global__ __launch_bounds__(256) void coarse_outer_kernel(CoarseOuterArgs<F, A> a) {
   __shared__ Cplx<A> ph[kCoEvecs][kCoMaxNC], phs[kCoEvecs][kCoMaxNC];
   const int NC = 2 * a.NV;
-  const int pty = blockIdx.x / a.volumeCBc, x_cb = blockIdx.x - pty * a.volumeCBc;
+  const int site = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int pty = site / a.volumeCBc, x_cb = site - pty * a.volumeCBc;
   const int r0 = (threadIdx.x >> 4) * B, c0 = (threadIdx.x & 15) * B;
   Cplx<A> acc[B][B];
 #pragma unroll
@@ -425,7 +432,7 @@ template <typename F, typename A, int B> __global__ __launch_bounds__(256) void 
         }
     }
   }
-  Cplx<A> *out = a.C + (int64_t)blockIdx.x * NC * NC;
+  Cplx<A> *out = a.C + (int64_t)site * NC * NC;
 #pragma unroll
   for (int i = 0; i < B; i++)
 #pragma unroll
