@@ -641,10 +641,13 @@ def test_full_size_cfg2_properties(hip):
         assert torch.max(torch.abs(off)).item() < 1e-13 * scale, iG
 
 
-def test_full_size_cfg3_local_shape_plus_minus_displacement_identity(hip):
+def test_full_size_cfg3_local_shape_plus_minus_displacement_identity(hip, monkeypatch):
     """configs[2] per-GPU shape (48x48x24x24), reduced N_ev: for Gamma = 1 the loop displaced by -k mu is the complex
     conjugate of the one displaced by +k mu shifted by k mu, so their lattice sums are complex conjugates -- a
-    size-independent link between the two signs, the path links and the tiled kernels (all four axes)."""
+    size-independent link between the two signs, the path links and the tiled kernels (all four axes).  Reflection is
+    switched OFF here: both signs are computed from the eigenvectors, so the identity links two independent computations
+    (with reflection on it would only restate what reflect_kernel enforces)."""
+    monkeypatch.setenv("MUGIQ_HIP_REFLECT", "0")
     X = (48, 48, 24, 24)
     nev = 6
     V = int(np.prod(X))
@@ -668,6 +671,7 @@ def test_full_size_cfg3_local_shape_plus_minus_displacement_identity(hip):
     prm = hip.MugiqLoopParam(gauge=gauge).set_displace_entry_string("+x:1,3;-x:1,3;+y:1,3;-y:1,3;+z:1,3;-z:1,3;+t:1,3;-t:1,3")
     loop = hip.Loop_Mugiq(prm, f, sg)
     loop.computeCoarseLoop()
+    assert all(loop.derivedFrom(i) < 0 for i in range(8))
     pos = loop.dataPos_d.view(loop.nLoop, 16, V)
     for axis in range(4):
         for k in range(3):
