@@ -18,6 +18,9 @@ the overlap did not hide), the process grid and the number of ranks RCCL saw (`n
 `python bench.py --gpus N` without a launcher starts its N ranks itself (children of this process, started before anything
 touches the GPU) and relays rank 0's line.
 
+At EVERY N one extra leg runs the SAME global problem (48^3 x 96, all 25 slots, N_ev = --strong-nev), unpartitioned at N = 1 and on the
+T-then-Z process grid otherwise, and reports it at the top level (`strong_scaling`): the speedup of the partitioned path from 1 to N GPUs.
+
 After the timed region (not part of `value`; skipped with --no-extra) the other legs of the path are measured too and
 reported under `also_measured`, each with its own roofline block, timed by HIP events inside the driver
 (mugiq_hip_loop_set_profiling):
@@ -74,8 +77,10 @@ def parse():
     ap.add_argument("--no-extra", action="store_true",
                     help="only the headline (use this under `rocprofv3 --stats`: the extra legs launch the headline kernel with "
                          "other shapes and would blur its per-kernel average)")
-    ap.add_argument("--extra", default="", help="comma list restricting the extra legs: displaced,forced,mg,cfg3 (N=1) / partitioned (N>1)")
+    ap.add_argument("--extra", default="", help="comma list restricting the extra legs: displaced,forced,strong,mg,cfg3 (N=1) / partitioned,strong (N>1)")
     ap.add_argument("--displaced-nev", type=int, default=400, help="eigenvectors of the displaced extra legs (configs[2]: 400 = 102 GB; 100 for a quick run)")
+    ap.add_argument("--strong-nev", type=int, default=32, help="eigenvectors of the strong-scaling leg (48^3 x 96 on every N; 32 fits one GPU "
+                                                              "with all 25 position-space slots and the reordered copy)")
     ap.add_argument("--extra-timeout", type=float, default=420.0, help="watchdog for the extra legs (s); the headline line is printed anyway")
     # overrides of the partitioned leg (rehearsals on a one-GPU box: MUGIQ_BENCH_BACKEND=gloo and a small lattice)
     ap.add_argument("--part-lattice", type=int, nargs=4, default=None, help="LOCAL lattice of the partitioned leg")
@@ -519,6 +524,27 @@ def extra_partitioned(hip, device, a, world, rank, backend):
     return out
 
 
+def extra_strong(hip, device, a, world, rank, backend):
+    """Strong scaling of the PARTITIONED path: the SAME global problem on every N -- configs[2]'s 48^3 x 96 lattice, all 25 slots,
+    momentum projection -- with as many eigenvectors as fit ONE GPU next to the position-space slots (N_ev = --strong-nev; halo
+    bytes and arithmetic both scale with N_ev, so the ratio that decides the scaling is that of the N_ev = 400 job).  N = 1 runs
+    it unpartitioned; N = 2, 4, 8 on 1x1x1x2, 1x1x1x4, 1x1x2x4 through GridComm (T first, then Z).  seconds(N = 1) / seconds(N) is
+    the speedup north_star asks about."""
+    grid = {1: (1, 1, 1, 1), 2: (1, 1, 1, 2), 4: (1, 1, 1, 4), 8: (1, 1, 2, 4)}.get(world)
+    if grid is None:
+        return {"error": "no process grid for %d ranks" % world}
+    G = (48, 48, 48, 96)
+    X = tuple(G[d] // grid[d] for d in range(4))
+    nev = a.strong_nev
+    comm = hip.GridComm(grid, device=device) if world > 1 else None
+    out = displaced_job(hip, device, X, nev, 8, comm, world, reps=1, backend=backend)
+    out["workload"] = "48x48x48x96 GLOBAL lattice on %d GPU(s) (process grid %dx%dx%dx%d, local %dx%dx%dx%d) fp64 N_ev=%d, entries %s, momentum " \
+                      "projection p^2<=9, driver OPT plan%s" % ((world,) + grid + X + (nev, ENTRIES_CFG2, (", halos over " + backend) if world > 1 else ""))
+    out["grid"] = list(grid)
+    out["global_sites"] = int(np.prod(G))
+    return out
+
+
 # ---- main --------------------------------------------------------------------------------------------------------------
 def self_launch(a):
     """`python bench.py --gpus N` typed without a launcher: start the N ranks as CHILDREN (python -m torch.distributed.run)
@@ -688,9 +714,11 @@ def main():
         want = [w for w in a.extra.split(",") if w]
         legs = ([("displaced_loops", "displaced", lambda: extra_displaced(hip, device, a.displaced_nev)),
                  ("forced_partition_displaced_loops", "forced", lambda: extra_forced(hip, device, a.displaced_nev)),
+                 ("strong_scaling_displaced_loops", "strong", lambda: extra_strong(hip, device, a, world, rank, backend)),
                  ("mg_coarse_loop", "mg", lambda: extra_mg(hip, device)),
                  ("cfg3_mixed_precision_ultra_local", "cfg3", lambda: extra_cfg3(hip, device))] if world == 1 else
-                [("partitioned_displaced_loops", "partitioned", lambda: extra_partitioned(hip, device, a, world, rank, backend))])
+                [("partitioned_displaced_loops", "partitioned", lambda: extra_partitioned(hip, device, a, world, rank, backend)),
+                 ("strong_scaling_displaced_loops", "strong", lambda: extra_strong(hip, device, a, world, rank, backend))])
         also = {}
         out["also_measured"] = also
 
@@ -723,6 +751,11 @@ def main():
             torch.cuda.empty_cache()
         _CFG2_INPUTS.clear()
         dog.cancel()
+        sd = also.get("strong_scaling_displaced_loops")
+        if sd and "error" not in sd:
+            # the same global problem at every N: seconds(N = 1) / seconds(N) is the speedup of the partitioned path
+            out["strong_scaling"] = {"workload": sd["workload"], "seconds": sd["seconds"], "global_sites_per_s_all_slots": sd["sites_per_s_all_slots"],
+                                     "halo_wait_ms_not_hidden": sd.get("halo", {}).get("wait_ms_not_hidden")}
         pd = also.get("partitioned_displaced_loops")
         if world > 1 and pd and "error" not in pd:
             # the partitioned configs[2] job at the top level: what a scaling curve of THIS path would be drawn from

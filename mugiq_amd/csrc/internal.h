@@ -35,6 +35,7 @@ int stream_workspace(void **ptr, size_t bytes, hipStream_t stream);
 int upload_table(void **dev, const void *host, size_t bytes, hipStream_t stream);
 int release_stream_scratch(hipStream_t stream);
 size_t eo_dft_x_lds_bytes(int precision, const int localL[4], int nPx, int *redOffsetElems);  // momproj.hip
+int eo_dft_x_time_chunk(int precision, const int localL[4], int nPx);                            // momproj.hip: 0 = the fused x step does not apply
 int fill_identity_links(const MugiqHipSpinorField *f, hipStream_t stream);  // displace.hip
 }  // namespace mugiq
 #include <vector>

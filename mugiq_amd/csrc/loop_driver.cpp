@@ -623,8 +623,7 @@ static bool fused_projection_applies(const MugiqHipLoop *lp) {
   std::vector<int> px;
   for (int n = 0; n < lp->Nmom; n++)
     if (std::find(px.begin(), px.end(), lp->momMatrix[3 * n]) == px.end()) px.push_back(lp->momMatrix[3 * n]);
-  const size_t tileBytes = eo_dft_x_lds_bytes(lp->loopPrecision, lp->localL, (int)px.size(), nullptr);
-  return tileBytes <= 64 * 1024 && lp->localL[2] <= 65535 && lp->nData <= 65535;
+  return eo_dft_x_time_chunk(lp->loopPrecision, lp->localL, (int)px.size()) >= 1 && lp->localL[2] <= 65535 && lp->nData <= 65535;
 }
 
 // Loop_Mugiq::performMomentumProjection  lib/loop_mugiq.cpp:322-434

@@ -211,6 +211,7 @@ template <typename F> struct EoDftArgs {
   int volumeCB, nPx, nPxPad, M;
   int tilesPerWg;      // pipelined kernel: consecutive y pairs per workgroup
   int redOffset;       // complex elements from the tile to the partial-sum area (0: the tile itself, single pass)
+  int tChunk;          // general kernel: time slices per tile (= X[3] unless the (x, t) rows of a y pair do not fit the LDS)
   const int *slotMap;  // NULL: every loop slot; else compact slot c of the output <- slot slotMap[c] of dataPos (a subset of the slots)
 };
 
@@ -232,10 +233,11 @@ template <typename F> __device__ inline void eo_dft_channels(const EoDftArgs<F> 
 constexpr int kEoCh = 8;  // p_x values per pass (accumulators per lane)
 
 // the sums of one staged tile (rows y0, y0 + 1 of plane z, all t) and their store; ends with the LDS still being read
-template <typename F> __device__ inline void eo_dft_x_sums(const EoDftArgs<F> &a, Cplx<F> *tile, int y0, int z, int idataTo) {
+// (t0, tn: the time slices [t0, t0 + tn) the tile holds -- all of them except in the chunked general kernel)
+template <typename F> __device__ inline void eo_dft_x_sums(const EoDftArgs<F> &a, Cplx<F> *tile, int y0, int z, int idataTo, int t0, int tn) {
   typedef F vec2 __attribute__((ext_vector_type(2)));
   const int Lx = a.X[0], Ly = a.X[1], Lt = a.X[3], ld = Lx + 1;
-  const int rows = kEoYG * Lt, lane = threadIdx.x & 63;
+  const int rows = kEoYG * tn, lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const Cplx<F> *phc = a.ph;
   for (int p0 = 0; p0 < a.nPx; p0 += kEoCh) {
@@ -280,7 +282,7 @@ template <typename F> __device__ inline void eo_dft_x_sums(const EoDftArgs<F> &a
             s.re += q.re;
             s.im += q.im;
           }
-          const int yy = rr / Lt, t = rr - yy * Lt;
+          const int yy = rr / tn, t = t0 + rr - yy * tn;
           a.out[((int64_t)(z * Ly + y0 + yy) * a.nPx + p0 + j) * a.M + t + Lt * idataTo] = s;
         }
       }
@@ -371,7 +373,7 @@ template <typename F> __global__ __launch_bounds__(256) void eo_dft_x_pipelined_
     st.commit(tile, sign);
     if (ty + 1 < te) st.fetch(src, ty + 1);
     __syncthreads();
-    eo_dft_x_sums(a, tile, ty * kEoYG, z, idataTo);
+    eo_dft_x_sums(a, tile, ty * kEoYG, z, idataTo, 0, a.X[3]);
   }
 }
 
@@ -462,19 +464,23 @@ template <int NKS, int MB> __global__ __launch_bounds__(256) void eo_dft_x_mfma_
   }
 }
 
-// General form (any Lx, Lt): one tile per workgroup, loads in batches of kEoLd per lane
+// General form (any Lx, Lt): one tile per workgroup, loads in batches of kEoLd per lane.  A tile holds the time slices
+// [t0, t0 + tn) of a y pair: all of them when they fit the LDS, else chunks of a.tChunk (48^3 x 96 on one GPU: 3 x 32) -- the
+// sums of different t are independent, so the chunks are independent workgroups.
 template <typename F> __global__ __launch_bounds__(256) void eo_dft_x_kernel(EoDftArgs<F> a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int Lx = a.X[0], Ly = a.X[1], Lz = a.X[2], Lt = a.X[3], ld = Lx + 1;  // padded rows: lanes walk the rows at a fixed x
-  Cplx<F> *tile = reinterpret_cast<Cplx<F> *>(smem);                         // [kEoYG * Lt rows][Lx + 1]; later the partial sums
-  const int y0 = blockIdx.x * kEoYG, z = blockIdx.y;
+  Cplx<F> *tile = reinterpret_cast<Cplx<F> *>(smem);                         // [kEoYG * tn rows][Lx + 1]; later the partial sums
+  const int tilesY = Ly / kEoYG, tc = blockIdx.x / tilesY;
+  const int t0 = tc * a.tChunk, tn = Lt - t0 < a.tChunk ? Lt - t0 : a.tChunk;
+  const int y0 = (blockIdx.x - tc * tilesY) * kEoYG, z = blockIdx.y;
   int ig, idataFrom, idataTo;
   eo_dft_channels(a, ig, idataFrom, idataTo);
   const F sign = (F)kGammaMapSign[ig];               // gammaMap->sign[ig]                    :93
   const Cplx<F> *src = a.in + (int64_t)idataFrom * 2 * a.volumeCB;
   // per (t, parity): the kEoYG * Lx/2 checkerboard entries of rows y0, y0+1 are contiguous ("run"); a wave fetches 64-entry
   // pieces of runs
-  const int hx = Lx >> 1, run = kEoYG * hx, nRuns = 2 * Lt;
+  const int hx = Lx >> 1, run = kEoYG * hx, nRuns = 2 * tn;
   typedef F vec2 __attribute__((ext_vector_type(2)));
   const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int chunks = (run + 63) / 64;
@@ -488,18 +494,18 @@ template <typename F> __global__ __launch_bounds__(256) void eo_dft_x_kernel(EoD
       const int tp = it / chunks, ch = it - tp * chunks;
       int r = ln + 64 * ch;
       r = r < run ? r : 0;
-      const int pty = tp & 1, t = tp >> 1;
+      const int pty = tp & 1, t = t0 + (tp >> 1);
       const int yy = r / hx, xh = r - yy * hx, y = y0 + yy;
       const int x = 2 * xh + ((pty - (y + z + t)) & 1);
       const int64_t x_cb = ((((int64_t)t * Lz + z) * Ly + y0) * Lx >> 1) + r;
       u[q] = __builtin_nontemporal_load(as_global(reinterpret_cast<const vec2 *>(src + (int64_t)pty * a.volumeCB + x_cb)));
-      dst[q] = (yy * Lt + t) * ld + x;
+      dst[q] = (yy * tn + (t - t0)) * ld + x;
     }
 #pragma unroll
     for (int q = 0; q < kEoLd; q++) tile[dst[q]] = Cplx<F>{sign * u[q].x, sign * u[q].y};
   }
   __syncthreads();
-  eo_dft_x_sums(a, tile, y0, z, idataTo);
+  eo_dft_x_sums(a, tile, y0, z, idataTo, t0, tn);
 }
 
 // LDS bytes of eo_dft_x_kernel: the tile, and the partial sums -- in the tile's place when one pass covers all rows (<= 64) and
@@ -510,6 +516,25 @@ size_t eo_dft_x_lds_bytes(int precision, const int localL[4], int nPx, int *redO
   const bool single = kEoYG * localL[3] <= 64 && nPx <= kEoCh;
   if (redOffsetElems) *redOffsetElems = single ? 0 : (int)tile;
   return (single ? std::max(tile, red) : tile + red) * 2 * (size_t)precision;
+}
+
+// Time slices per tile of the fused reorder + x step: all of them if the tile then fits 64 KiB of LDS (the pipelined and the
+// matrix-pipe forms need that), else the largest chunk whose tile does and whose rows go through in one pass; 0 if even one
+// time slice does not fit (Lx of several thousand).
+int eo_dft_x_time_chunk(int precision, const int localL[4], int nPx) {
+  if (eo_dft_x_lds_bytes(precision, localL, nPx, nullptr) <= 64 * 1024) return localL[3];
+  int L[4] = {localL[0], localL[1], localL[2], localL[3]};
+  int tcMax = 0;
+  for (int tc = std::min(localL[3], 64 / kEoYG); tc >= 1; tc--) {
+    L[3] = tc;
+    if (eo_dft_x_lds_bytes(precision, L, nPx, nullptr) <= 64 * 1024) {
+      tcMax = tc;
+      break;
+    }
+  }
+  if (tcMax == 0) return 0;
+  const int nChunks = (localL[3] + tcMax - 1) / tcMax;
+  return (localL[3] + nChunks - 1) / nChunks;  // even chunks
 }
 
 // the plan: distinct p_x, distinct (p_x, p_y) pairs, and the tables of the three steps
@@ -668,8 +693,11 @@ static int launch_separable(void *C, const void *A, const void *dataPosEO, int n
   int firstStep = 0;
   if (dataPosEO != nullptr) {  // step x straight from the even-odd buffer (A, the reordered copy, is not needed)
     EoDftArgs<F> e;
-    const size_t shmem = eo_dft_x_lds_bytes((int)sizeof(F), localL, (int)P.px.size(), &e.redOffset);
-    MUGIQ_REQUIRE(shmem <= 64 * 1024 && localL[2] <= 65535 && nData <= 65535, "performMomentumProjection: lattice too large for the fused reorder + x step");
+    const int tChunk = eo_dft_x_time_chunk((int)sizeof(F), localL, (int)P.px.size());
+    MUGIQ_REQUIRE(tChunk >= 1 && localL[2] <= 65535 && nData <= 65535, "performMomentumProjection: lattice too large for the fused reorder + x step");
+    int Lc[4] = {localL[0], localL[1], localL[2], tChunk};
+    const size_t shmem = eo_dft_x_lds_bytes((int)sizeof(F), Lc, (int)P.px.size(), &e.redOffset);
+    e.tChunk = tChunk;
     e.in = static_cast<const Cplx<F> *>(dataPosEO);
     e.out = t1;
     e.ph = ph_d + phXT;
@@ -684,7 +712,7 @@ static int launch_separable(void *C, const void *A, const void *dataPosEO, int n
     e.M = M;
     e.slotMap = slotMap_h ? int_d + slotOff : nullptr;
     const int run = kEoYG * localL[0] / 2, tiles = localL[1] / kEoYG;
-    const bool pipelined = run <= 64 && (2 * localL[3] + 64 / run - 1) / (64 / run) <= 4 * kEoLd;
+    const bool pipelined = tChunk == localL[3] && run <= 64 && (2 * localL[3] + 64 / run - 1) / (64 / run) <= 4 * kEoLd;
     // the sums on the matrix pipe where it applies (fp64; one pass: <= 64 rows, <= 8 distinct p_x; Lx = 24, 32, 48 or 64):
     // 1.95 ms against 2.06 ms for the vector form at 48.48.24.24 x 25 slots (profiles/r02_eo_dft_x_kernel_stats_*.csv);
     // MUGIQ_HIP_EO_MFMA = 0 keeps the vector form
@@ -715,7 +743,8 @@ static int launch_separable(void *C, const void *A, const void *dataPosEO, int n
         hipLaunchKernelGGL((eo_dft_x_pipelined_kernel<F>), dim3((tiles + perWg - 1) / perWg, localL[2], nData), dim3(256), shmem, stream, e);
     } else {
       e.tilesPerWg = 1;
-      hipLaunchKernelGGL((eo_dft_x_kernel<F>), dim3(tiles, localL[2], nData), dim3(256), shmem, stream, e);
+      const int nChunks = (localL[3] + tChunk - 1) / tChunk;
+      hipLaunchKernelGGL((eo_dft_x_kernel<F>), dim3(tiles * nChunks, localL[2], nData), dim3(256), shmem, stream, e);
     }
     MUGIQ_CHECK_HIP(hipGetLastError());
     firstStep = 1;

@@ -294,10 +294,14 @@ def test_convert_and_project_in_one_call(hip, prec, X, nLoop, coord, tot):
 
 @pytest.mark.parametrize("prec", [8, 4])
 @pytest.mark.parametrize("X,pxs", [((4, 2, 2, 40), [0, 1]), ((12, 2, 2, 4), list(range(-5, 6))), ((8, 4, 2, 36), list(range(-4, 6))),
-                                   ((32, 2, 2, 32), [0, 3, -1])])
+                                   ((32, 2, 2, 32), [0, 3, -1]),
+                                   # (x, t) rows of a y pair beyond 64 KiB of LDS: the tile is cut into chunks of time slices
+                                   # (48 x 48: two chunks of 24 in fp64, one tile in fp32; 48 x 96 -- one GPU's view of
+                                   # 48^3 x 96: three of 32 / two of 48; 64 x 40 with 11 p_x: ragged chunks, several passes)
+                                   ((48, 2, 2, 48), [0, 1, -1, 2]), ((48, 2, 4, 96), [0, -2, 1]), ((64, 2, 2, 40), list(range(-5, 6)))])
 def test_convert_and_project_multi_pass_shapes(hip, prec, X, pxs):
     """The fused reorder + x step keeps one row (y, t) per lane and 8 distinct p_x per pass: more than 64 rows (Lt > 32)
-    and more than 8 distinct p_x go through several passes over the staged tile."""
+    and more than 8 distinct p_x go through several passes over the staged tile; tiles beyond the LDS are cut along t."""
     rng = np.random.default_rng(47)
     V = int(np.prod(X))
     nLoop, nData = 2, 32
