@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace mugiq {
@@ -58,11 +59,14 @@ template <int ORDER> __device__ inline int64_t comp_offset16(int comp, int64_t s
   else return ((int64_t)(comp >> 1) * stride + idx) * 2 + (comp & 1);
 }
 
-// PHL bounds the staging loads per lane and eigenvector (ceil(np * 192 / #threads))
-template <typename F, typename A, int ORDER, int DIR, int SIGN, int PHL>
-__global__ __launch_bounds__(64 * 9) void tile16_displaced_contract_kernel(Tile16Args<F, A> a) {
+// PHL bounds the staging loads per lane and eigenvector (ceil(np * 192 / #threads)).
+// GLDS (fp64 FLOAT2 storage; round 3): the tile goes global -> LDS directly (global_load_lds_dwordx4) into THREE buffers -- one
+// consumed, two in flight -- exactly as in csrc/fused_tile.hip: no stage registers, no ds_write pass.  The staging index is
+// already linear in the thread (element e <-> thread e mod #threads), which is the lane-linear image the transfer wants.
+template <typename F, typename A, int ORDER, int DIR, int SIGN, int PHL, bool GLDS>
+__device__ __forceinline__ void tile16_body(const Tile16Args<F, A> &a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  Cplx<F> *tileBase = reinterpret_cast<Cplx<F> *>(smem);  // 2 x [PHL * #threads] (double-buffered over the eigenvectors)
+  Cplx<F> *tileBase = reinterpret_cast<Cplx<F> *>(smem);  // 2 (GLDS: 3) x [PHL * #threads] (buffered over the eigenvectors)
   const int nthreads = blockDim.x;
   const size_t tileElems = (size_t)PHL * nthreads;        // padded: commits are unconditional
   const int t = threadIdx.x, lane = t & 63;
@@ -205,24 +209,11 @@ __global__ __launch_bounds__(64 * 9) void tile16_displaced_contract_kernel(Tile1
     __builtin_amdgcn_s_barrier();                        \
     asm volatile("" ::: "memory");                       \
   }
-// One step: eigenvector n_ is in LDS buffer n_ % 2; `stage` holds eigenvector n_+1.  Commit n_+1 into the other buffer,
-// refill `stage` with n_ + kDepth + 1, consume n_, one barrier.
-#define MUGIQ_T16_STEP(n_, stage, GUARD)                                                                               \
+// the arithmetic of one eigenvector (scaled by s_) on the tile buffer tile_
+#define MUGIQ_T16_COMPUTE(tile_, s_)                                                                                   \
   {                                                                                                                    \
-    const Cplx<F> *tile = tileBase + (size_t)((n_) & 1) * tileElems;                                                   \
-    const A s = sigPre;                                                                                                \
-    const Cplx<F> *bodyNow = bodyPre;                                                                                  \
-    {                                                                                                                  \
-      const int nb_ = (n_) + kDepth + 2 < a.nVec ? (n_) + kDepth + 2 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1; \
-      bodyPre = MUGIQ_T16_BODY(nb_);                                                                                   \
-      sigPre = MUGIQ_T16_SIGMA(ns_);                                                                                   \
-    }                                                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    if (GUARD == 0 || (n_) + 1 < a.nVec) {                                                                             \
-      Cplx<F> *nxt = tileBase + (size_t)(((n_) + 1) & 1) * tileElems;                                                  \
-      _Pragma("unroll") for (int i = 0; i < PHL; i++) nxt[commit_index(i)] = Cplx<F>{stage[i].x, stage[i].y};          \
-    }                                                                                                                  \
-    if (GUARD == 0 || (n_) + kDepth + 1 < a.nVec) MUGIQ_T16_FETCH_AT(bodyNow, (n_) + kDepth + 1, stage)                \
+    const Cplx<F> *tile = tile_;                                                                                       \
+    const A s = s_;                                                                                                    \
     if (computes) {                                                                                                    \
       const Cplx<F> *tl = tile + (ppL * 12) * kT16Cols + col;                                                          \
       const Cplx<F> *ts = tile + (ppS * 12 + half * 6) * kT16Cols + colS; /* spins 2*half, 2*half + 1 */               \
@@ -251,9 +242,80 @@ __global__ __launch_bounds__(64 * 9) void tile16_displaced_contract_kernel(Tile1
         }                                                                                                              \
       }                                                                                                                \
     }                                                                                                                  \
+  }
+// One step: eigenvector n_ is in LDS buffer n_ % 2; `stage` holds eigenvector n_+1.  Commit n_+1 into the other buffer,
+// refill `stage` with n_ + kDepth + 1, consume n_, one barrier.
+#define MUGIQ_T16_STEP(n_, stage, GUARD)                                                                               \
+  {                                                                                                                    \
+    const A sNow = sigPre;                                                                                             \
+    const Cplx<F> *bodyNow = bodyPre;                                                                                  \
+    {                                                                                                                  \
+      const int nb_ = (n_) + kDepth + 2 < a.nVec ? (n_) + kDepth + 2 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1; \
+      bodyPre = MUGIQ_T16_BODY(nb_);                                                                                   \
+      sigPre = MUGIQ_T16_SIGMA(ns_);                                                                                   \
+    }                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    if (GUARD == 0 || (n_) + 1 < a.nVec) {                                                                             \
+      Cplx<F> *nxt = tileBase + (size_t)(((n_) + 1) & 1) * tileElems;                                                  \
+      _Pragma("unroll") for (int i = 0; i < PHL; i++) nxt[commit_index(i)] = Cplx<F>{stage[i].x, stage[i].y};          \
+    }                                                                                                                  \
+    if (GUARD == 0 || (n_) + kDepth + 1 < a.nVec) MUGIQ_T16_FETCH_AT(bodyNow, (n_) + kDepth + 1, stage)                \
+    MUGIQ_T16_COMPUTE(tileBase + (size_t)((n_) & 1) * tileElems, sNow)                                                 \
     MUGIQ_T16_BARRIER()                                                                                                \
   }
 
+  if constexpr (GLDS) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (global_load_lds is a device-only builtin: the host pass of hipcc must not see it)
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // this lane's share of eigenvector n_ -> tile buffer buf_: PHL transfers of 64 x 16 bytes (elements wave * 64 + lane + #threads * i)
+#define MUGIQ_T16_GLDS(bodyExpr_, n_, buf_)                                                                            \
+  {                                                                                                                    \
+    const Cplx<F> *body_ = bodyExpr_;                                                                                  \
+    const Cplx<F> *gh_ = ghostBase + (int64_t)(n_)*a.ghost_vec_stride;                                                 \
+    Cplx<F> *dst_ = (buf_) + (size_t)wave * 64;                                                                        \
+    _Pragma("unroll") for (int i = 0; i < PHL; i++) {                                                                  \
+      const Cplx<F> *ptr_ = (((sghost >> i) & 1u) ? gh_ : body_) + soff[i];                                            \
+      __builtin_amdgcn_global_load_lds(as_global(reinterpret_cast<const vec2 *>(ptr_)), (lds_void *)(dst_ + (size_t)i * nthreads), 16, 0, 0); \
+    }                                                                                                                  \
+  }
+#define MUGIQ_T16_GSTEP(n_, cur_, nxt2_, STEADY)                                                                       \
+  {                                                                                                                    \
+    const A sNow = sigPre;                                                                                             \
+    const Cplx<F> *bodyNow = bodyPre;                                                                                  \
+    if (STEADY || (n_) + 1 < a.nVec) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PHL) : "memory");                        \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
+    MUGIQ_T16_BARRIER()                                                                                                \
+    if (STEADY || (n_) + 2 < a.nVec) MUGIQ_T16_GLDS(bodyNow, (n_) + 2, nxt2_)                                          \
+    MUGIQ_T16_COMPUTE(cur_, sNow)                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    {                                                                                                                  \
+      const int nb_ = (n_) + 3 < a.nVec ? (n_) + 3 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1;      \
+      bodyPre = MUGIQ_T16_BODY(nb_);                                                                                   \
+      sigPre = MUGIQ_T16_SIGMA(ns_);                                                                                   \
+    }                                                                                                                  \
+  }
+    Cplx<F> *const buf0 = tileBase, *const buf1 = tileBase + tileElems, *const buf2 = tileBase + 2 * tileElems;
+    const int last = a.nVec - 1;
+    MUGIQ_T16_GLDS(MUGIQ_T16_BODY(0), 0, buf0)
+    MUGIQ_T16_GLDS(MUGIQ_T16_BODY((1 < last ? 1 : last)), (1 < last ? 1 : last), buf1)  // (unconditional: known count in flight)
+    const Cplx<F> *bodyPre = MUGIQ_T16_BODY((2 < last ? 2 : last));
+    A sigPre = MUGIQ_T16_SIGMA(0);
+    int n = 0;
+    for (; n + 4 < a.nVec; n += 3) {
+      MUGIQ_T16_GSTEP(n, buf0, buf2, 1)
+      MUGIQ_T16_GSTEP(n + 1, buf1, buf0, 1)
+      MUGIQ_T16_GSTEP(n + 2, buf2, buf1, 1)
+    }
+    for (; n < a.nVec; n += 3) {  // n % 3 == 0 here
+      MUGIQ_T16_GSTEP(n, buf0, buf2, 0)
+      if (n + 1 < a.nVec) MUGIQ_T16_GSTEP(n + 1, buf1, buf0, 0)
+      if (n + 2 < a.nVec) MUGIQ_T16_GSTEP(n + 2, buf2, buf1, 0)
+    }
+#undef MUGIQ_T16_GSTEP
+#undef MUGIQ_T16_GLDS
+#endif
+  } else {
   // prologue: eigenvector 0 -> LDS buffer 0; the next kDepth eigenvectors in flight in the stage registers (clamped,
   // unconditional loads: the steady-state loop is entered with a KNOWN number of loads in flight)
   MUGIQ_T16_FETCH(0, stageC)
@@ -280,7 +342,9 @@ __global__ __launch_bounds__(64 * 9) void tile16_displaced_contract_kernel(Tile1
     if constexpr (kDepth == 3)
       if (n + 2 < a.nVec) MUGIQ_T16_STEP(n + 2, stageC, 1)
   }
+  }  // register-staged form
 #undef MUGIQ_T16_STEP
+#undef MUGIQ_T16_COMPUTE
   // ---- epilogue: the two lane halves of an item hold complementary halves of the 4x4 colour-traced spin matrix of the
   // same 16 sites.  Exchange them with wavefront shuffles (lane ^ 16), then each half takes 8 of the 16 gamma traces.
   {
@@ -305,6 +369,10 @@ __global__ __launch_bounds__(64 * 9) void tile16_displaced_contract_kernel(Tile1
   }
 }
 
+template <typename F, typename A, int ORDER, int DIR, int SIGN, int PHL, bool GLDS>
+__global__ __launch_bounds__(64 * 9) void tile16_displaced_contract_kernel(Tile16Args<F, A> a) {
+  tile16_body<F, A, ORDER, DIR, SIGN, PHL, GLDS>(a);
+}
 #undef MUGIQ_T16_FETCH
 #undef MUGIQ_T16_FETCH_AT
 #undef MUGIQ_T16_BODY
@@ -368,15 +436,22 @@ template <typename F, typename A, int ORDER> static int launch_tile16(Tile16Args
   const int nthreads = 64 * waves;
   const int phl = (a.np * kT16Row + nthreads - 1) / nthreads;
   const int PHLsel = phl <= 2 ? 2 : (phl <= 4 ? 4 : 8);
-  const size_t shmem = 2 * sizeof(Cplx<F>) * (size_t)PHLsel * nthreads;
+  // global -> LDS staging with three buffers: fp64 FLOAT2 storage (MUGIQ_HIP_TILE16_GLDS=0: register staging, two buffers)
+  bool glds = std::is_same<F, double>::value && ORDER == 2 && 3 * sizeof(Cplx<F>) * (size_t)PHLsel * nthreads <= 160 * 1024;
+  if (const char *e = getenv("MUGIQ_HIP_TILE16_GLDS")) glds = glds && atoi(e) != 0;
+  const size_t shmem = (glds ? 3 : 2) * sizeof(Cplx<F>) * (size_t)PHLsel * nthreads;
   unsigned nblocks = dir == 0 ? (unsigned)(a.volumeCB / (a.m * kT16Cols)) : (unsigned)(((a.numCols + kT16Cols - 1) / kT16Cols) * a.jtCount);
   a.blockOrder = 2;
   if (const char *e = getenv("MUGIQ_HIP_TILE_ORDER")) a.blockOrder = atoi(e) & 2;
   if (nblocks % 8 != 0) a.blockOrder = 0;
   const dim3 grid(nblocks), block(nthreads);
-#define MUGIQ_T16_LAUNCH(D, S, P)                                                                                     \
+#define MUGIQ_T16_LAUNCH(D, S, P) \
+  if constexpr (std::is_same<F, double>::value && ORDER == 2) { \
+    if (glds) MUGIQ_T16_LAUNCH_G(D, S, P, true) else MUGIQ_T16_LAUNCH_G(D, S, P, false) \
+  } else MUGIQ_T16_LAUNCH_G(D, S, P, false)
+#define MUGIQ_T16_LAUNCH_G(D, S, P, G)                                                                                \
   {                                                                                                                   \
-    auto kern = tile16_displaced_contract_kernel<F, A, ORDER, D, S, P>;                                               \
+    auto kern = tile16_displaced_contract_kernel<F, A, ORDER, D, S, P, G>;                                            \
     if (shmem > 64 * 1024)                                                                                            \
       MUGIQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, a);                                                          \
@@ -391,6 +466,7 @@ template <typename F, typename A, int ORDER> static int launch_tile16(Tile16Args
   }
 #undef MUGIQ_T16_CASE
 #undef MUGIQ_T16_LAUNCH
+#undef MUGIQ_T16_LAUNCH_G
   MUGIQ_CHECK_HIP(hipGetLastError());
   return MUGIQ_HIP_SUCCESS;
 }
