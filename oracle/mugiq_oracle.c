@@ -8,8 +8,8 @@
  * PARITY UNPINNED: the reference holds no golden vectors for this path; this file is
  * cross-checked against the numpy oracle and the analytic KATs in tests/.
  *
- * Build: make -C oracle   (gcc -O3 -march=native -fcx-limited-range -fopenmp; rebuilt on the box it runs on if the
- * instruction set differs -- see oracle/c_oracle.py)
+ * Build: make -C oracle   (gcc -O3 -fcx-limited-range -fopenmp; the site-block routine is compiled for avx512f / avx2 / baseline
+ * x86-64 side by side and picked at load time, so the library built in one container runs on the GPU box's host)
  */
 #include <complex.h>
 #include <stdint.h>

@@ -16,4 +16,5 @@ done
 cd $R
 python3 tools/pmc_traffic.py $O/pmc_FETCH_SIZE_counter_collection.csv $O/pmc_WRITE_SIZE_counter_collection.csv loop_contract_kernel "$(python3 -c "import json;print(json.load(open('$O/bench.json'))['config']['workload'])")" $O/traffic_latest.json 1048576
 python3 tools/pmc_traffic_extra.py $O/pmc_FETCH_SIZE_counter_collection.csv $O/pmc_WRITE_SIZE_counter_collection.csv $O/traffic_extra_latest.json 400
+for c in FETCH_SIZE WRITE_SIZE; do python3 tools/slim_pmc_csv.py $O/pmc_${c}_counter_collection.csv $O/pmc_${c}_mugiq.csv; done
 ls $O
