@@ -151,10 +151,16 @@ __global__ __launch_bounds__(BLOCK) void loop_contract_kernel(ContractArgs<A> a)
 struct ContractTune {
   int block, depth, nt, swz;
 };
-static ContractTune contract_tune(bool same) {
+static ContractTune contract_tune(bool same, bool fp64Storage) {
   // sweep on MI355X, 32^4 x 200 fp64 (profiles/r01_contract_sweep.txt): non-temporal loads +4 %; block size and prefetch
-  // depth within 1 % of each other (4-6 waves/SIMD already cover the latency); XCD-contiguous order +2 %
+  // depth within 1 % of each other INSIDE one process (4-6 waves/SIMD already cover the latency); XCD-contiguous order +2 %.
+  // Across processes the kernel's time moves with where its 40 GB landed (profiles/r03_headline_layout.txt), and there the
+  // variants differ: over 8 fresh processes each, workgroups of 512 with three eigenvectors in flight averaged 6.65 ms (6.40-6.86,
+  // 0.91-0.98 of the read probe of their process) against 6.83 ms (6.51-7.08, 0.86-0.94) for 256 / two
+  // (profiles/r03_headline_tune.txt) -- faster on average and less exposed to a bad placement.  fp64 storage only: the other
+  // storage types showed no such difference (profiles/r02_contract_cfg3_sweep.txt) and the mixed mode is built for 256.
   ContractTune t{256, 2, 1, 1};
+  if (same && fp64Storage) t = ContractTune{512, 3, 1, 1};
   if (const char *e = getenv("MUGIQ_HIP_CONTRACT_TUNE")) {
     int b = 0, d = 0, n = 0, w = 0;
     if (sscanf(e, "%d,%d,%d,%d", &b, &d, &n, &w) >= 3 && (b == 64 || b == 128 || b == 256 || b == 512) && d >= 1 && d <= 3 && (n == 0 || n == 1)) {
@@ -224,7 +230,7 @@ static int launch_contract(void *loop_d, const MugiqHipSpinorField *L, const Mug
   a.volumeCB = L[0].volumeCB;
   a.stride = L[0].stride;
   a.parity_offset = L[0].parity_offset;
-  const ContractTune t = contract_tune(same);
+  const ContractTune t = contract_tune(same, std::is_same<F, double>::value && std::is_same<A, double>::value);
   a.xcdSwizzle = (t.swz && (((2 * a.volumeCB + t.block - 1) / t.block) % 8 == 0)) ? 1 : 0;
   if (same) launch_block<F, A, ORDER, true>(a, t, stream);
   else launch_block<F, A, ORDER, false>(a, t, stream);
