@@ -79,8 +79,8 @@ def parse():
                          "other shapes and would blur its per-kernel average)")
     ap.add_argument("--extra", default="", help="comma list restricting the extra legs: displaced,forced,strong,mg,cfg3 (N=1) / partitioned,strong (N>1)")
     ap.add_argument("--displaced-nev", type=int, default=400, help="eigenvectors of the displaced extra legs (configs[2]: 400 = 102 GB; 100 for a quick run)")
-    ap.add_argument("--strong-nev", type=int, default=32, help="eigenvectors of the strong-scaling leg (48^3 x 96 on every N; 32 fits one GPU "
-                                                              "with all 25 position-space slots and the reordered copy)")
+    ap.add_argument("--strong-nev", type=int, default=48, help="eigenvectors of the strong-scaling leg (48^3 x 96 on every N; 48 fit one GPU "
+                                                              "next to all 25 position-space slots with room to spare: 98 + 68 GB; 64 is the most that fits)")
     ap.add_argument("--extra-timeout", type=float, default=420.0, help="watchdog for the extra legs (s); the headline line is printed anyway")
     # overrides of the partitioned leg (rehearsals on a one-GPU box: MUGIQ_BENCH_BACKEND=gloo and a small lattice)
     ap.add_argument("--part-lattice", type=int, nargs=4, default=None, help="LOCAL lattice of the partitioned leg")
