@@ -38,7 +38,6 @@ Usage: python bench.py --gpus N --steps K --warmup W        (N>1: launched by to
 """
 import argparse
 import hashlib
-import copy
 import re
 import json
 import os
