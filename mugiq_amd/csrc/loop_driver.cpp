@@ -417,17 +417,20 @@ static int prepare_halo(MugiqHipLoop *lp, int id) {
     MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&h.evPacked, hipEventDisableTiming));
     MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&h.evHalo, hipEventDisableTiming));
   }
-  const int ph = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_PREPARE, id, lp->stream, (double)bytes);
-  if ((st = build_path_links(lp, id, h.E))) return st;
+  if ((st = build_path_links(lp, id, h.E))) return st;  // compute stream: the entry's kernels read them there
   if ((st = scratch_alloc(lp, &h.gsend, bytes, false))) return st;
   if ((st = scratch_alloc(lp, &h.grecv, bytes, false))) return st;
   // all of these outlive the entries processed in between: move them from the per-entry list to the held list
   for (void *q : lp->scratch) lp->held.push_back(q);
   lp->scratch.clear();
+  // The face layers are packed ON THE HALO STREAM: the pack reads the eigenvectors only (the caller has ordered them behind
+  // evHaloStart), so it needs nothing of the compute stream -- 25 GB read + written (12 ms at configs[2]) that used to sit in
+  // front of the first entry now run under it (the tiled kernels leave half of the memory bandwidth unused).
   const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
-  if ((st = mugiq_hip_pack_face_layers(h.gsend, lp->eVecs.data(), lp->nEv, dir, high, stop, lp->stream))) return st;
-  MUGIQ_CHECK_HIP(hipEventRecord(h.evPacked, lp->stream));
-  phase_end(lp, ph, lp->stream);
+  const int ph = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_PREPARE, id, lp->commStream, (double)bytes);
+  if ((st = mugiq_hip_pack_face_layers(h.gsend, lp->eVecs.data(), lp->nEv, dir, high, stop, lp->commStream))) return st;
+  MUGIQ_CHECK_HIP(hipEventRecord(h.evPacked, lp->commStream));
+  phase_end(lp, ph, lp->commStream);
   h.posted = true;
   return MUGIQ_HIP_SUCCESS;
 }
@@ -1085,6 +1088,10 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
   // partitioned entries (interior tiles before the halo is waited for), and the reflected entries last.
   std::vector<int> order;
   order.push_back(-1);
+  int earlyEntry = -2;        // OPT plan with halos to post: the entry that runs before they are packed (-2: none)
+  bool postHalos = false;
+  bool grouped = false;
+  std::vector<char> aheadFlags;
   if (basic) {
     for (int id = 0; id < lp->nDispEntries; id++) {
       lp->derivedFrom[id] = -1;
@@ -1111,31 +1118,7 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
       if (const char *e = getenv("MUGIQ_HIP_REFLECT_MOM")) on = atoi(e) != 0;
       lp->momReflect = on && anyDerived && fused_projection_applies(lp) && momenta_negation_table(lp->momMatrix.data(), lp->Nmom, neg);
     }
-    const bool grouped = lp->haveComm && lp->comm.group_begin && lp->comm.group_end;
-    if (any) {
-      if ((st = ensure_comm_stream(lp))) return st;
-      for (int id = 0; id < lp->nDispEntries; id++)
-        if (ahead[id] && (st = prepare_halo(lp, id))) return st;
-      double haloBytes = 0;
-      for (int id = 0; id < lp->nDispEntries; id++)
-        if (lp->halo[id].posted) {
-          // (the transfer cannot start before the last pack kernel: wait here so that the phase brackets the transfer only)
-          MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, lp->halo[id].evPacked, 0));
-          haloBytes += (double)halo_bytes(lp, id);
-        }
-      const int phHalo = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_TRANSFER, -1, lp->commStream, haloBytes);
-      if (grouped && (st = lp->comm.group_begin(lp->comm.ctx))) return set_error(MUGIQ_HIP_ERROR_HIP, "group_begin callback failed with status %d", st);
-      for (int id = 0; id < lp->nDispEntries && !st; id++)
-        if (lp->halo[id].posted) st = send_halo(lp, id);
-      if (grouped) {
-        const int st2 = lp->comm.group_end(lp->comm.ctx, lp->commStream);
-        if (!st && st2) st = set_error(MUGIQ_HIP_ERROR_HIP, "group_end callback failed with status %d", st2);
-      }
-      if (st) return st;
-      phase_end(lp, phHalo, lp->commStream);
-      for (int id = 0; id < lp->nDispEntries; id++)
-        if (lp->halo[id].posted) MUGIQ_CHECK_HIP(hipEventRecord(lp->halo[id].evHalo, lp->commStream));
-    }
+    grouped = lp->haveComm && lp->comm.group_begin && lp->comm.group_end;
     for (int pass = 0; pass < 3; pass++)
       for (int id = 0; id < lp->nDispEntries; id++) {
         const bool derived = lp->derivedFrom[id] >= 0, part = lp->commDim[lp->dispDir[id]] != 0;
@@ -1150,13 +1133,32 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
       order.erase(order.begin());
       order.push_back(-1);
     }
+      // (the else of `if (basic)` stays open: the halos are posted below, once the order is known)
+    earlyEntry = -2;
+    if (any) {
+      if ((st = ensure_comm_stream(lp))) return st;
+      // the halo stream starts behind what the compute stream holds so far (e.g. the prolongation that writes the eigenvectors)
+      MUGIQ_CHECK_HIP(hipEventRecord(lp->evPacked, lp->stream));
+      MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, lp->evPacked, 0));
+      // One entry that needs no halo goes FIRST, before the halos are packed: a pack kernel launched ahead of it fills the
+      // device and the entry's kernels queue up behind it (measured: the compute stream made no progress during the 12 ms of
+      // packing even with the packs on the halo stream); launched behind a tiled kernel that is already resident -- one
+      // workgroup per CU, LDS-bound occupancy -- the packs and the transfer run in its shadow instead.
+      for (int id : order)
+        if (id >= 0 && lp->derivedFrom[id] < 0 && !lp->commDim[lp->dispDir[id]]) {
+          earlyEntry = id;
+          break;
+        }
+    }
+    postHalos = any;
+    aheadFlags = ahead;
   }
   lp->posReflectPending = false;
-  for (int id : order) {
-    if (id == -1 && !basic && lp->carryUltra && lp->ultraCarried) continue;  // produced by a displaced entry's pass
+  auto run_one = [&](int id) -> int {
+    if (id == -1 && !basic && lp->carryUltra && lp->ultraCarried) return MUGIQ_HIP_SUCCESS;  // produced by a displaced entry's pass
     if (id >= 0 && !basic && lp->momReflect && lp->derivedFrom[id] >= 0) {   // derived in momentum space; position space on request
       lp->posReflectPending = true;
-      continue;
+      return MUGIQ_HIP_SUCCESS;
     }
     long long bufOffset;
     size_t bufByteSize;
@@ -1202,7 +1204,40 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
       free_scratch(lp);
     }
     phase_end(lp, ph, lp->stream);
+    return st;
+  };
+  // the halos of the plan: link fields, packed face layers, one transfer group on the halo stream
+  auto post_halos = [&]() -> int {
+    const std::vector<char> &ahead = aheadFlags;
+      for (int id = 0; id < lp->nDispEntries; id++)
+        if (ahead[id] && (st = prepare_halo(lp, id))) return st;
+      double haloBytes = 0;
+      for (int id = 0; id < lp->nDispEntries; id++)
+        if (lp->halo[id].posted) {
+          // (the transfer cannot start before the last pack kernel: wait here so that the phase brackets the transfer only)
+          MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, lp->halo[id].evPacked, 0));
+          haloBytes += (double)halo_bytes(lp, id);
+        }
+      const int phHalo = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_TRANSFER, -1, lp->commStream, haloBytes);
+      if (grouped && (st = lp->comm.group_begin(lp->comm.ctx))) return set_error(MUGIQ_HIP_ERROR_HIP, "group_begin callback failed with status %d", st);
+      for (int id = 0; id < lp->nDispEntries && !st; id++)
+        if (lp->halo[id].posted) st = send_halo(lp, id);
+      if (grouped) {
+        const int st2 = lp->comm.group_end(lp->comm.ctx, lp->commStream);
+        if (!st && st2) st = set_error(MUGIQ_HIP_ERROR_HIP, "group_end callback failed with status %d", st2);
+      }
+      if (st) return st;
+      phase_end(lp, phHalo, lp->commStream);
+      for (int id = 0; id < lp->nDispEntries; id++)
+        if (lp->halo[id].posted) MUGIQ_CHECK_HIP(hipEventRecord(lp->halo[id].evHalo, lp->commStream));
+    return MUGIQ_HIP_SUCCESS;
+  };
+  if (earlyEntry >= 0) st = run_one(earlyEntry);
+  if (!st && postHalos) st = post_halos();
+  for (int id : order) {
     if (st) break;
+    if (id == earlyEntry) continue;
+    st = run_one(id);
   }
   {
     hipError_t e = hipStreamSynchronize(lp->stream);
