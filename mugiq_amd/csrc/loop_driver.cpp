@@ -1133,8 +1133,7 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
       order.erase(order.begin());
       order.push_back(-1);
     }
-      // (the else of `if (basic)` stays open: the halos are posted below, once the order is known)
-    earlyEntry = -2;
+    earlyEntry = -2;  // (the halos are posted further down, once the order is known)
     if (any) {
       if ((st = ensure_comm_stream(lp))) return st;
       // the halo stream starts behind what the compute stream holds so far (e.g. the prolongation that writes the eigenvectors)
@@ -1209,27 +1208,27 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
   // the halos of the plan: link fields, packed face layers, one transfer group on the halo stream
   auto post_halos = [&]() -> int {
     const std::vector<char> &ahead = aheadFlags;
-      for (int id = 0; id < lp->nDispEntries; id++)
-        if (ahead[id] && (st = prepare_halo(lp, id))) return st;
-      double haloBytes = 0;
-      for (int id = 0; id < lp->nDispEntries; id++)
-        if (lp->halo[id].posted) {
-          // (the transfer cannot start before the last pack kernel: wait here so that the phase brackets the transfer only)
-          MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, lp->halo[id].evPacked, 0));
-          haloBytes += (double)halo_bytes(lp, id);
-        }
-      const int phHalo = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_TRANSFER, -1, lp->commStream, haloBytes);
-      if (grouped && (st = lp->comm.group_begin(lp->comm.ctx))) return set_error(MUGIQ_HIP_ERROR_HIP, "group_begin callback failed with status %d", st);
-      for (int id = 0; id < lp->nDispEntries && !st; id++)
-        if (lp->halo[id].posted) st = send_halo(lp, id);
-      if (grouped) {
-        const int st2 = lp->comm.group_end(lp->comm.ctx, lp->commStream);
-        if (!st && st2) st = set_error(MUGIQ_HIP_ERROR_HIP, "group_end callback failed with status %d", st2);
+    for (int id = 0; id < lp->nDispEntries; id++)
+      if (ahead[id] && (st = prepare_halo(lp, id))) return st;
+    double haloBytes = 0;
+    for (int id = 0; id < lp->nDispEntries; id++)
+      if (lp->halo[id].posted) {
+        // (the transfer cannot start before the last pack kernel: wait here so that the phase brackets the transfer only)
+        MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, lp->halo[id].evPacked, 0));
+        haloBytes += (double)halo_bytes(lp, id);
       }
-      if (st) return st;
-      phase_end(lp, phHalo, lp->commStream);
-      for (int id = 0; id < lp->nDispEntries; id++)
-        if (lp->halo[id].posted) MUGIQ_CHECK_HIP(hipEventRecord(lp->halo[id].evHalo, lp->commStream));
+    const int phHalo = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_TRANSFER, -1, lp->commStream, haloBytes);
+    if (grouped && (st = lp->comm.group_begin(lp->comm.ctx))) return set_error(MUGIQ_HIP_ERROR_HIP, "group_begin callback failed with status %d", st);
+    for (int id = 0; id < lp->nDispEntries && !st; id++)
+      if (lp->halo[id].posted) st = send_halo(lp, id);
+    if (grouped) {
+      const int st2 = lp->comm.group_end(lp->comm.ctx, lp->commStream);
+      if (!st && st2) st = set_error(MUGIQ_HIP_ERROR_HIP, "group_end callback failed with status %d", st2);
+    }
+    if (st) return st;
+    phase_end(lp, phHalo, lp->commStream);
+    for (int id = 0; id < lp->nDispEntries; id++)
+      if (lp->halo[id].posted) MUGIQ_CHECK_HIP(hipEventRecord(lp->halo[id].evHalo, lp->commStream));
     return MUGIQ_HIP_SUCCESS;
   };
   if (earlyEntry >= 0) st = run_one(earlyEntry);
