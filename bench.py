@@ -155,6 +155,8 @@ def cpu_baseline(fields, sigmas, X, prec, order, budget_s):
     from oracle import c_oracle
     nev = len(fields)
     vcb = fields[0].volumeCB
+    if "OMP_NUM_THREADS" not in os.environ:
+        c_oracle.set_num_threads(c_oracle.usable_cpus())   # affinity mask capped by the cgroup CPU quota, not every hardware thread
     threads = c_oracle.num_threads()
     S = min(vcb, max(32768, 2048 * threads))      # sample: 2*S sites x all N_ev eigenvectors
     cdt = np.complex128 if prec == 8 else np.complex64
@@ -183,8 +185,9 @@ def cpu_baseline(fields, sigmas, X, prec, order, budget_s):
     return {"value": sites_per_s, "unit": "sites/s", "cores": threads, "kind": "port",
             "host_GBps": sites_per_s * nev * 24 * prec / 1e9,
             "sample": "%d sites x %d eigenvectors (first %d checkerboard sites of each parity of the bench fields = %d sites per "
-                      "thread, pages first-touched by the reading threads), %d passes in %.1f s, oracle/mugiq_oracle.c with OpenMP, "
-                      "blocks of 8 sites" % (2 * S, nev, S, 2 * S // threads, passes, el)}, loop, S
+                      "thread, pages first-touched by the reading threads), %d passes in %.1f s, oracle/mugiq_oracle.c with OpenMP (threads = the "
+                      "CPUs this job may use: affinity mask capped by the cgroup quota; the host has %d hardware threads), chunks of "
+                      "256 sites x all eigenvectors, blocks of 8 sites" % (2 * S, nev, S, 2 * S // threads, passes, el, os.cpu_count() or 0)}, loop, S
 
 
 # ---- roofline helpers --------------------------------------------------------------------------------------------------

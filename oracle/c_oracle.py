@@ -17,6 +17,8 @@ def load():
             raise ImportError("%s missing: run `make -C oracle`" % _PATH)
         _lib = ctypes.CDLL(_PATH)
         _lib.oracle_num_threads.restype = ctypes.c_int
+        _lib.oracle_set_num_threads.restype = None
+        _lib.oracle_set_num_threads.argtypes = [ctypes.c_int]
         for name in ("oracle_loop_contract_f64", "oracle_loop_contract_f32"):
             f = getattr(_lib, name)
             f.restype = None
@@ -36,6 +38,29 @@ def first_touch_copy(src, n_planes, S):
     dst = np.empty_like(src)                     # freshly mapped, untouched
     lib.oracle_first_touch_copy(dst.ctypes.data, src.ctypes.data, n_planes, S, src.nbytes // (2 * n_planes * S))
     return dst
+
+
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands a job 16 of its 256
+    hardware threads that way; OpenMP's default would start one thread per hardware thread and have them throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p_))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def set_num_threads(n):
+    load().oracle_set_num_threads(int(n))
 
 
 def num_threads():
