@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--displaced-nev", type=int, default=400, help="eigenvectors of the displaced extra legs (configs[2]: 400 = 102 GB; 100 for a quick run)")
     ap.add_argument("--strong-nev", type=int, default=48, help="eigenvectors of the strong-scaling leg (48^3 x 96 on every N; 48 fit one GPU "
                                                               "next to all 25 position-space slots with room to spare: 98 + 68 GB; 64 is the most that fits)")
+    ap.add_argument("--emulate-link-GBps", type=float, default=75.0,
+                    help="forced-partition leg, second pass: hold the halo stream busy for bytes / this rate per (axis, direction) link, so that "
+                         "the overlap schedule is exercised at about the pace of one xGMI link per neighbour (0: skip the pass)")
     ap.add_argument("--extra-timeout", type=float, default=420.0, help="watchdog for the extra legs (s); the headline line is printed anyway")
     # overrides of the partitioned leg (rehearsals on a one-GPU box: MUGIQ_BENCH_BACKEND=gloo and a small lattice)
     ap.add_argument("--part-lattice", type=int, nargs=4, default=None, help="LOCAL lattice of the partitioned leg")
@@ -403,7 +406,7 @@ def extra_displaced(hip, device, nev=400):
     return out
 
 
-def extra_forced(hip, device, nev=400):
+def extra_forced(hip, device, nev=400, emulate_GBps=0.0):
     """configs[2] as ONE rank of its 1x1x2x4 grid sees it: the partitioned code path forced on z and t with the rank as its own
     forward and backward neighbour (MugiqHipComm.partitioned = QUDA's comm_dim_partitioned_set).  Everything the 8-GPU run does
     on a rank happens here at full size -- gauge borders R = 2 through sendrecv, `stop` face layers of all eigenvectors packed
@@ -417,6 +420,17 @@ def extra_forced(hip, device, nev=400):
     out["workload"] = "48x48x24x24 fp64 N_ev=%d, z and t FORCED-partitioned on one rank (self-neighbour: device copies, no xGMI), " \
                       "entries %s, momentum projection p^2<=9, driver OPT plan, halos posted ahead" % (nev, ENTRIES_CFG2)
     out["forced_partition"] = [0, 0, 1, 1]
+    if emulate_GBps > 0:
+        # the same job once more with the self-messages slowed down to the pace of an xGMI link (see GridComm): what the schedule
+        # hides and what it does not when the halo takes as long as it would between GPUs
+        comm2 = hip.GridComm((1, 1, 1, 1), device=device, force_partitioned=(0, 0, 1, 1), emulate_link_GBps=emulate_GBps)
+        emu = displaced_job(hip, device, X, nev, 8, comm2, 1, reps=1, fields=fields, gauge=gauge)
+        h = emu.get("halo", {})
+        out["emulated_link"] = {"GBps_per_link": emulate_GBps, "seconds": emu["seconds"], "halo_transfer_ms": h.get("transfer_ms"),
+                                "halo_wait_ms_not_hidden": h.get("wait_ms_not_hidden"), "phase_ms": emu["phase_ms"],
+                                "note": "EMULATION on one GPU: the self-neighbour copies are followed by a spin kernel on the halo stream until bytes / rate "
+                                        "have passed; the z and t messages of the transfer group count as two links side by side.  No xGMI, no RCCL: it "
+                                        "shows the overlap schedule (what waits for what), not a transport"}
     return out
 
 
@@ -715,7 +729,7 @@ def main():
         torch.cuda.empty_cache()
         want = [w for w in a.extra.split(",") if w]
         legs = ([("displaced_loops", "displaced", lambda: extra_displaced(hip, device, a.displaced_nev)),
-                 ("forced_partition_displaced_loops", "forced", lambda: extra_forced(hip, device, a.displaced_nev)),
+                 ("forced_partition_displaced_loops", "forced", lambda: extra_forced(hip, device, a.displaced_nev, a.emulate_link_GBps)),
                  ("strong_scaling_displaced_loops", "strong", lambda: extra_strong(hip, device, a, world, rank, backend)),
                  ("mg_coarse_loop", "mg", lambda: extra_mg(hip, device)),
                  ("cfg3_mixed_precision_ultra_local", "cfg3", lambda: extra_cfg3(hip, device))] if world == 1 else

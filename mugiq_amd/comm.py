@@ -34,14 +34,20 @@ def host_array(ptr, n_real, precision):
 
 
 class GridComm:
-    def __init__(self, grid, device=None, force_partitioned=(0, 0, 0, 0)):
+    def __init__(self, grid, device=None, force_partitioned=(0, 0, 0, 0), emulate_link_GBps=0.0):
         """grid = ranks along (x, y, z, t).  torch.distributed must be initialised; every rank must construct this
         (it creates the sub-groups collectively).
         force_partitioned[d] != 0 on an axis of extent 1: comm_dim_partitioned(d) is 1 there all the same (QUDA's
         comm_dim_partitioned_set / `--partition`), i.e. the driver runs its partitioned code path along d -- ghost zones,
         packed face layers, halo messages, interior / boundary tiles, gauge borders through sendrecv -- with this rank as
         its own neighbour (the message is a device copy, or a send-to-self with loopback_through_transport).  It lets ONE
-        GPU run the halo machinery at the full per-GPU size; the result must equal the unpartitioned run."""
+        GPU run the halo machinery at the full per-GPU size; the result must equal the unpartitioned run.
+        emulate_link_GBps > 0 (measurement aid, self-neighbour messages only): a message to self is a device copy, i.e. it is over in
+        a fraction of the time the same bytes take over one xGMI link, and the overlap schedule of the driver (halos posted ahead,
+        interior tiles first, boundary tiles after the halo event) is never put to the test.  With this set, the stream that carries
+        the message is additionally held busy (a spin kernel on one wave) until bytes / rate have passed -- messages of different
+        (axis, direction) inside one transfer group count as different links and run side by side, like different peers over xGMI.
+        The data are the same; only the time at which the halo event fires changes."""
         self.grid = tuple(int(g) for g in grid)
         self.force_partitioned = tuple(1 if f else 0 for f in force_partitioned)
         self.device = torch.device(device) if device is not None else torch.device("cpu")
@@ -52,6 +58,9 @@ class GridComm:
         # message through the transport as well (a send to self inside one batch): ONE rank then exercises the real
         # isend / irecv path of the backend.
         self.loopback_through_transport = False
+        self.emulate_link_GBps = float(emulate_link_GBps)
+        self._emu_bytes = {}          # (dim, direction) -> bytes sent to self since the last delay
+        self._emu_cycles_per_s = None
         if not dist.is_initialized():
             # one process without a process group: only the 1x1x1x1 grid, whose every message is a copy to self (forced
             # partitioning on one device); the reduce / gather / bcast callbacks are never reached with size == 1
@@ -106,6 +115,11 @@ class GridComm:
         if dst == self.rank and not self.loopback_through_transport:
             # extent 1 along `dim` (forced partitioning): my own face is my ghost zone -- a copy on the current stream
             recv.copy_(send, non_blocking=True)
+            if self.emulate_link_GBps > 0 and send.is_cuda:
+                key = (dim, direction)
+                self._emu_bytes[key] = self._emu_bytes.get(key, 0) + send.numel() * send.element_size()
+                if self._group is None:
+                    self._emu_delay()
             return
         stage = self.backend == "gloo" and send.is_cuda
         s = send.cpu() if stage else send
@@ -124,8 +138,28 @@ class GridComm:
         batch (ncclGroupStart/End under torch's batch_isend_irecv), i.e. use their xGMI links at the same time."""
         self._group = []
 
+    def _emu_delay(self):
+        """hold the current stream for what the slowest emulated link needs for the bytes handed to it (see __init__)"""
+        if not self._emu_bytes:
+            return
+        seconds = max(self._emu_bytes.values()) / (self.emulate_link_GBps * 1e9)
+        self._emu_bytes = {}
+        if self._emu_cycles_per_s is None:           # calibrate the spin kernel's clock once
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            cal = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(cal):
+                torch.cuda._sleep(1000)
+                e0.record()
+                torch.cuda._sleep(20_000_000)
+                e1.record()
+            cal.synchronize()
+            self._emu_cycles_per_s = 20_000_000 / (e0.elapsed_time(e1) * 1e-3)
+        torch.cuda._sleep(int(seconds * self._emu_cycles_per_s))
+
     def group_end(self):
         pending, self._group = self._group, None
+        if self.emulate_link_GBps > 0:
+            self._emu_delay()
         if not pending:
             return
         ops = []

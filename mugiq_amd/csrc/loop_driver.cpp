@@ -67,6 +67,7 @@ struct MugiqHipLoop_s {
   hipStream_t stream = nullptr;
   // halo transfers run on their own stream so they overlap the interior part of the fused contraction
   hipStream_t commStream = nullptr;
+  hipStream_t packStream = nullptr;  // the face layers are packed here, block by block, while the previous block travels
   hipEvent_t evPacked = nullptr, evHalo = nullptr;
   // ---- data buffers (include/loop_mugiq.h:49-57, lib/loop_mugiq.cpp:101-158)
   long long nElemMomTotPerLoop = 0, nElemMomLocPerLoop = 0, nElemPosLocPerLoop = 0;
@@ -107,6 +108,9 @@ struct MugiqHipLoop_s {
   struct HaloPost {
     void *gsend = nullptr, *grecv = nullptr;
     hipEvent_t evPacked = nullptr, evHalo = nullptr;
+    // the halo travels in blocks of eigenvectors: evPackedBlk[b] (pack stream) / evBlock[b] (halo stream: block b has landed)
+    std::vector<hipEvent_t> evPackedBlk, evBlock;
+    int nBlocks = 0, blockN = 0;
     bool posted = false;
     std::vector<MugiqHipSpinorField> E;  // path-link fields built ahead (their small face exchanges go first)
   };
@@ -398,6 +402,7 @@ static int reserve_plan_buffers(MugiqHipLoop *lp) {
 }
 
 static int ensure_comm_stream(MugiqHipLoop *lp) {
+  if (!lp->packStream) MUGIQ_CHECK_HIP(hipStreamCreateWithFlags(&lp->packStream, hipStreamNonBlocking));
   if (!lp->commStream) {
     MUGIQ_CHECK_HIP(hipStreamCreateWithFlags(&lp->commStream, hipStreamNonBlocking));
     MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&lp->evPacked, hipEventDisableTiming));
@@ -406,10 +411,10 @@ static int ensure_comm_stream(MugiqHipLoop *lp) {
   return MUGIQ_HIP_SUCCESS;
 }
 
-// Halo of entry `id` posted ahead, step 1: link fields (their small face exchanges happen here, at once), ghost buffers
-// for ALL eigenvectors, pack kernel.  (Whether an entry is posted ahead is plan_opt's decision.)
+// Halo of entry `id` posted ahead, step 1: link fields (their small face exchanges happen here, at once), ghost buffers for
+// ALL eigenvectors, and the cut into blocks of eigenvectors the halo travels in.  (Whether an entry is posted ahead is
+// plan_opt's decision.)
 static int prepare_halo(MugiqHipLoop *lp, int id) {
-  const int dir = lp->dispDir[id], sign = lp->dispSign[id], stop = lp->dispStop[id];
   const size_t bytes = halo_bytes(lp, id);
   int st;
   MugiqHipLoop::HaloPost &h = lp->halo[id];
@@ -423,32 +428,69 @@ static int prepare_halo(MugiqHipLoop *lp, int id) {
   // all of these outlive the entries processed in between: move them from the per-entry list to the held list
   for (void *q : lp->scratch) lp->held.push_back(q);
   lp->scratch.clear();
-  // The face layers are packed ON THE HALO STREAM: the pack reads the eigenvectors only (the caller has ordered them behind
-  // evHaloStart), so it needs nothing of the compute stream -- 25 GB read + written (12 ms at configs[2]) that used to sit in
-  // front of the first entry now run under it (the tiled kernels leave half of the memory bandwidth unused).
-  const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
-  const int ph = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_PREPARE, id, lp->commStream, (double)bytes);
-  if ((st = mugiq_hip_pack_face_layers(h.gsend, lp->eVecs.data(), lp->nEv, dir, high, stop, lp->commStream))) return st;
-  MUGIQ_CHECK_HIP(hipEventRecord(h.evPacked, lp->commStream));
-  phase_end(lp, ph, lp->commStream);
+  // Blocks of about 2 GiB (at most 8): the first block is on its way after a fraction of the packing, and the boundary tiles
+  // of the first blocks run while the last ones still travel -- with ONE message the transfer could not start before all
+  // face layers were packed (12 ms at configs[2]) and no boundary tile before the last byte had landed.  MUGIQ_HIP_HALO_BLOCKS
+  // fixes the number (1 = the single message of round 2).
+  int nb = (int)std::min<size_t>(8, std::max<size_t>(1, (bytes + ((size_t)1 << 31) - 1) >> 31));
+  if (const char *e = getenv("MUGIQ_HIP_HALO_BLOCKS")) nb = std::max(1, std::min(64, atoi(e)));
+  nb = std::min(nb, lp->nEv);
+  h.blockN = (lp->nEv + nb - 1) / nb;
+  h.nBlocks = (lp->nEv + h.blockN - 1) / h.blockN;
+  while ((int)h.evBlock.size() < h.nBlocks) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+    MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    h.evPackedBlk.push_back(e0);
+    h.evBlock.push_back(e1);
+  }
   h.posted = true;
   return MUGIQ_HIP_SUCCESS;
 }
 
-// step 2: hand the packed layers to the transport on the halo stream (possibly inside a transfer group)
-static int send_halo(MugiqHipLoop *lp, int id) {
-  const int dir = lp->dispDir[id], sign = lp->dispSign[id];
-  const size_t bytes = halo_bytes(lp, id);
-  const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
-  MugiqHipLoop::HaloPost &h = lp->halo[id];
-  MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, h.evPacked, 0));
-  const int st = lp->comm.sendrecv(lp->comm.ctx, h.gsend, h.grecv, bytes, dir, high ? +1 : -1, lp->commStream);
-  if (st) return set_error(MUGIQ_HIP_ERROR_HIP, "halo sendrecv callback failed with status %d", st);
+// step 2: block b of every posted entry -- packed on the pack stream, handed to the transport on the halo stream (the entries
+// of one block inside one transfer group: different axes, different links)
+static int send_halo_block(MugiqHipLoop *lp, int b, bool grouped) {
+  int st = MUGIQ_HIP_SUCCESS;
+  for (int id = 0; id < lp->nDispEntries; id++) {
+    MugiqHipLoop::HaloPost &h = lp->halo[id];
+    if (!h.posted || b >= h.nBlocks) continue;
+    const int dir = lp->dispDir[id], sign = lp->dispSign[id], stop = lp->dispStop[id];
+    const int n0 = b * h.blockN, nv = std::min(h.blockN, lp->nEv - n0);
+    const size_t perVec = halo_bytes(lp, id) / (size_t)lp->nEv;
+    const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
+    if ((st = mugiq_hip_pack_face_layers(static_cast<char *>(h.gsend) + perVec * n0, &lp->eVecs[n0], nv, dir, high, stop, lp->packStream))) return st;
+    MUGIQ_CHECK_HIP(hipEventRecord(h.evPackedBlk[b], lp->packStream));
+    MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, h.evPackedBlk[b], 0));
+  }
+  if (grouped && (st = lp->comm.group_begin(lp->comm.ctx))) return set_error(MUGIQ_HIP_ERROR_HIP, "group_begin callback failed with status %d", st);
+  for (int id = 0; id < lp->nDispEntries && !st; id++) {
+    MugiqHipLoop::HaloPost &h = lp->halo[id];
+    if (!h.posted || b >= h.nBlocks) continue;
+    const int n0 = b * h.blockN, nv = std::min(h.blockN, lp->nEv - n0);
+    const size_t perVec = halo_bytes(lp, id) / (size_t)lp->nEv;
+    const int high = (lp->dispSign[id] == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
+    const int rc = lp->comm.sendrecv(lp->comm.ctx, static_cast<char *>(h.gsend) + perVec * n0, static_cast<char *>(h.grecv) + perVec * n0,
+                                     perVec * nv, lp->dispDir[id], high ? +1 : -1, lp->commStream);
+    if (rc) st = set_error(MUGIQ_HIP_ERROR_HIP, "halo sendrecv callback failed with status %d", rc);
+  }
+  if (grouped) {
+    const int st2 = lp->comm.group_end(lp->comm.ctx, lp->commStream);
+    if (!st && st2) st = set_error(MUGIQ_HIP_ERROR_HIP, "group_end callback failed with status %d", st2);
+  }
+  if (st) return st;
+  for (int id = 0; id < lp->nDispEntries; id++) {
+    MugiqHipLoop::HaloPost &h = lp->halo[id];
+    if (h.posted && b < h.nBlocks) MUGIQ_CHECK_HIP(hipEventRecord(h.evBlock[b], lp->commStream));
+  }
   return MUGIQ_HIP_SUCCESS;
 }
 
 // ---- the fused plan -------------------------------------------------------------------------------------------
-static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
+// part_sel: 0 = the whole entry; for an entry whose halo was posted ahead 1 = the interior tiles only, 2 = the boundary tiles
+// only (the driver runs the interiors of ALL such entries before the first boundary: nothing then waits for a halo while there
+// is still work that needs none)
+static int entry_fused(MugiqHipLoop *lp, int id, void *slot0, int part_sel = 0) {
   const int dir = lp->dispDir[id], sign = lp->dispSign[id];
   const bool part = lp->commDim[dir] != 0;
   const int stop = lp->dispStop[id], start = lp->dispStart[id];
@@ -470,21 +512,31 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0) {
     // the halo of all eigenvectors was posted at the start of the compute: interior tiles, then (once it has landed) the
     // boundary tiles
     MugiqHipLoop::HaloPost &h = lp->halo[id];
-    int ph = phase_begin(lp, MUGIQ_HIP_PHASE_ENTRY_INTERIOR, id, lp->stream);
-    if ((st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, lp->eVecs.data(), lp->sigma.data(), lp->nEv,
-                                                                links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
-                                                                h.grecv, stop, MUGIQ_HIP_REGION_INTERIOR | MUGIQ_HIP_REGION_OVERWRITE, lp->stream)))
-      return st;
-    phase_end(lp, ph, lp->stream);
-    ph = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_WAIT, id, lp->stream);  // idle time of the compute stream: what the overlap did not hide
-    MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->stream, h.evHalo, 0));
-    phase_end(lp, ph, lp->stream);
-    ph = phase_begin(lp, MUGIQ_HIP_PHASE_ENTRY_BOUNDARY, id, lp->stream);
-    st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, lp->eVecs.data(), lp->sigma.data(), lp->nEv,
-                                                           links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim, h.grecv,
-                                                           stop, MUGIQ_HIP_REGION_BOUNDARY | MUGIQ_HIP_REGION_OVERWRITE, lp->stream);
-    phase_end(lp, ph, lp->stream);
-    return st;
+    int ph;
+    if (part_sel != 2) {
+      ph = phase_begin(lp, MUGIQ_HIP_PHASE_ENTRY_INTERIOR, id, lp->stream);
+      if ((st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, lp->eVecs.data(), lp->sigma.data(), lp->nEv,
+                                                                  links.data(), kv.data(), (int)kv.size(), dir, sign, lp->commDim,
+                                                                  h.grecv, stop, MUGIQ_HIP_REGION_INTERIOR | MUGIQ_HIP_REGION_OVERWRITE, lp->stream)))
+        return st;
+      phase_end(lp, ph, lp->stream);
+    }
+    if (part_sel == 1) return MUGIQ_HIP_SUCCESS;
+    // boundary tiles, block of eigenvectors by block as the halo lands: the first block writes the boundary sites, the others add
+    const size_t perVec = halo_bytes(lp, id) / (size_t)lp->nEv;
+    for (int b = 0; b < h.nBlocks; b++) {
+      const int n0 = b * h.blockN, nv = std::min(h.blockN, lp->nEv - n0);
+      ph = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_WAIT, id, lp->stream);  // idle time of the compute stream: what the overlap did not hide
+      MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->stream, h.evBlock[b], 0));
+      phase_end(lp, ph, lp->stream);
+      ph = phase_begin(lp, MUGIQ_HIP_PHASE_ENTRY_BOUNDARY, id, lp->stream);
+      st = mugiq_hip_displaced_loop_contraction_fused_region(slot0, lp->loopPrecision, &lp->eVecs[n0], &lp->sigma[n0], nv, links.data(), kv.data(),
+                                                             (int)kv.size(), dir, sign, lp->commDim, static_cast<char *>(h.grecv) + perVec * n0, stop,
+                                                             MUGIQ_HIP_REGION_BOUNDARY | (b == 0 ? MUGIQ_HIP_REGION_OVERWRITE : 0), lp->stream);
+      phase_end(lp, ph, lp->stream);
+      if (st) return st;
+    }
+    return MUGIQ_HIP_SUCCESS;
   }
   // eigenvector blocks: bounded by the ghost-layer buffers when the dimension is partitioned
   int nb = lp->nEv;
@@ -1153,6 +1205,16 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
     aheadFlags = ahead;
   }
   lp->posReflectPending = false;
+  std::vector<int> pendingBoundary;  // entries whose interior tiles are out and whose boundary tiles wait for their halo
+  auto run_boundaries = [&]() -> int {
+    for (int id : pendingBoundary) {
+      void *slot0 = static_cast<char *>(lp->dataPos_d) + (size_t)lp->nElemPosLocPerLoop * lp->nLoopOffset[id] * cb;
+      if ((st = entry_fused(lp, id, slot0, 2))) return st;
+      free_scratch(lp);
+    }
+    pendingBoundary.clear();
+    return MUGIQ_HIP_SUCCESS;
+  };
   auto run_one = [&](int id) -> int {
     if (id == -1 && !basic && lp->carryUltra && lp->ultraCarried) return MUGIQ_HIP_SUCCESS;  // produced by a displaced entry's pass
     if (id >= 0 && !basic && lp->momReflect && lp->derivedFrom[id] >= 0) {   // derived in momentum space; position space on request
@@ -1197,7 +1259,10 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
     } else {
       if (basic) st = entry_basic(lp, id, slot0);
       else if (lp->derivedFrom[id] >= 0) st = entry_reflected(lp, id, lp->derivedFrom[id], slot0);
-      else st = entry_fused(lp, id, slot0);
+      else if (split && lp->halo[id].posted) {
+        st = entry_fused(lp, id, slot0, 1);  // interior tiles now; the boundary tiles once every entry's interior is through
+        pendingBoundary.push_back(id);
+      } else st = entry_fused(lp, id, slot0);
       // No host synchronisation between entries: every user of this entry's scratch is ordered on lp->stream (the halo
       // stream's part was waited for by the boundary kernels), so the next entry may take the buffers over at once.
       free_scratch(lp);
@@ -1211,24 +1276,20 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
     for (int id = 0; id < lp->nDispEntries; id++)
       if (ahead[id] && (st = prepare_halo(lp, id))) return st;
     double haloBytes = 0;
+    int maxBlocks = 0;
     for (int id = 0; id < lp->nDispEntries; id++)
       if (lp->halo[id].posted) {
-        // (the transfer cannot start before the last pack kernel: wait here so that the phase brackets the transfer only)
-        MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, lp->halo[id].evPacked, 0));
         haloBytes += (double)halo_bytes(lp, id);
+        maxBlocks = std::max(maxBlocks, lp->halo[id].nBlocks);
       }
+    // the pack stream starts where the halo stream starts (behind what the compute stream held when the compute began)
+    MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->packStream, lp->evPacked, 0));
+    const int phPack = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_PREPARE, -1, lp->packStream, haloBytes);
     const int phHalo = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_TRANSFER, -1, lp->commStream, haloBytes);
-    if (grouped && (st = lp->comm.group_begin(lp->comm.ctx))) return set_error(MUGIQ_HIP_ERROR_HIP, "group_begin callback failed with status %d", st);
-    for (int id = 0; id < lp->nDispEntries && !st; id++)
-      if (lp->halo[id].posted) st = send_halo(lp, id);
-    if (grouped) {
-      const int st2 = lp->comm.group_end(lp->comm.ctx, lp->commStream);
-      if (!st && st2) st = set_error(MUGIQ_HIP_ERROR_HIP, "group_end callback failed with status %d", st2);
-    }
-    if (st) return st;
+    for (int b = 0; b < maxBlocks; b++)
+      if ((st = send_halo_block(lp, b, grouped))) return st;
+    phase_end(lp, phPack, lp->packStream);
     phase_end(lp, phHalo, lp->commStream);
-    for (int id = 0; id < lp->nDispEntries; id++)
-      if (lp->halo[id].posted) MUGIQ_CHECK_HIP(hipEventRecord(lp->halo[id].evHalo, lp->commStream));
     return MUGIQ_HIP_SUCCESS;
   };
   if (earlyEntry >= 0) st = run_one(earlyEntry);
@@ -1236,8 +1297,12 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
   for (int id : order) {
     if (st) break;
     if (id == earlyEntry) continue;
-    st = run_one(id);
+    // reflected entries and the ultra-local loop come after the computed ones: the boundary tiles go before them (a reflected
+    // entry reads the complete slots of its source)
+    if (!pendingBoundary.empty() && (id < 0 || lp->derivedFrom[id] >= 0)) st = run_boundaries();
+    if (!st) st = run_one(id);
   }
+  if (!st && !pendingBoundary.empty()) st = run_boundaries();
   {
     hipError_t e = hipStreamSynchronize(lp->stream);
     if (!st && e != hipSuccess) st = set_error(MUGIQ_HIP_ERROR_HIP, "computeCoarseLoop: %s", hipGetErrorString(e));
@@ -1417,7 +1482,10 @@ int mugiq_hip_loop_destroy(MugiqHipLoop *lp) {  // freeDataMemory, lib/loop_mugi
   for (auto &h : lp->halo) {
     if (h.evPacked) (void)hipEventDestroy(h.evPacked);
     if (h.evHalo) (void)hipEventDestroy(h.evHalo);
+    for (hipEvent_t e : h.evPackedBlk) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h.evBlock) (void)hipEventDestroy(e);
   }
+  if (lp->packStream) (void)hipStreamDestroy(lp->packStream);
   for (hipEvent_t e : lp->events) (void)hipEventDestroy(e);
   if (lp->evPacked) (void)hipEventDestroy(lp->evPacked);
   if (lp->evHalo) (void)hipEventDestroy(lp->evHalo);
