@@ -66,7 +66,7 @@ ms = np.array(ms)
 alg = V * (a.nev * 192 + 256)
 out = {"label": a.label, "mode": a.mode, "pad": a.pad, "stagger_bytes": a.stagger_bytes if a.mode == "stagger" else 0, "tune": a.tune,
        "min_ms": float(ms.min()), "median_ms": float(np.median(ms)), "max_ms": float(ms.max()), "GBps_median": alg / np.median(ms) / 1e6,
-       "base_mod_2MiB": [int(b.data_ptr() % (2 << 20)) for b in bufs[:3]]}
+       "base_mod_2MiB": [int(b.data_ptr() % (2 << 20)) for b in bufs[:3]], "base_ptr": hex(bufs[0].data_ptr()), "loop_ptr": hex(loop.data_ptr())}
 if big is not None:
     pm = []
     for r in range(5):
