@@ -392,10 +392,11 @@ typedef struct MugiqHipComm_s {
   /* MPI_Bcast from world rank 0 (lib/loop_mugiq.cpp:424) */
   int (*bcast)(void *ctx, void *buf_h, size_t n_real, int precision);
   /* Optional (both NULL or both set).  The OPT plan posts the eigenvector halos of ALL partitioned entries at the start
-   * of a compute: between group_begin and group_end it issues one sendrecv per such entry, all on the same stream and
-   * to different neighbours.  A transport that can run them concurrently (different xGMI links: ncclGroupStart/End;
-   * MPI_Isend/Irecv + Waitall) may defer them until group_end(ctx, stream); one without these members runs every
-   * sendrecv as it comes. */
+   * of a compute, in blocks of eigenvectors (about 2 GiB per message): for every block it issues, between group_begin and
+   * group_end, one sendrecv per such entry -- all on the same stream, to different neighbours -- and the groups of
+   * successive blocks follow each other on that stream.  A transport that can run the messages of a group concurrently
+   * (different xGMI links: ncclGroupStart/End; MPI_Isend/Irecv + Waitall) may defer them until group_end(ctx, stream); one
+   * without these members runs every sendrecv as it comes. */
   int (*group_begin)(void *ctx);
   int (*group_end)(void *ctx, void *stream);
   /* comm_dim_partitioned(d) beyond grid[d] > 1 (QUDA: comm_dim_partitioned_set(d), the `--partition` switch of its tests):
