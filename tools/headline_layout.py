@@ -52,16 +52,16 @@ for b in bufs:
     fields.append(hip.SpinorField(X, 8, 2, pad=a.pad, data=b))
 sig = 0.01 + 0.002 * np.arange(a.nev)
 loop = torch.zeros(16 * V, dtype=torch.complex128, device=dev)
-ms = []
-for r in range(a.warmup + a.steps):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+# launches queued back to back like bench.py's timed loop (the host runs ahead of the device: with a synchronisation per launch the
+# ~0.3 ms Python spends building 200 descriptors would sit between the two events of every launch)
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.warmup + a.steps)]
+for e0, e1 in ev:
     loop.zero_()
     e0.record()
     hip.performLoopContractionBatched(loop, fields, fields, sig)
     e1.record()
-    torch.cuda.synchronize()
-    if r >= a.warmup:
-        ms.append(e0.elapsed_time(e1))
+torch.cuda.synchronize()
+ms = [e0.elapsed_time(e1) for e0, e1 in ev[a.warmup:]]
 ms = np.array(ms)
 alg = V * (a.nev * 192 + 256)
 out = {"label": a.label, "mode": a.mode, "pad": a.pad, "stagger_bytes": a.stagger_bytes if a.mode == "stagger" else 0, "tune": a.tune,

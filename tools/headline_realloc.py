@@ -24,16 +24,15 @@ for rnd in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
     big = torch.empty(nev * per, dtype=torch.complex128, device=dev)
     big.view(torch.float64).normal_(generator=torch.Generator(device=dev).manual_seed(1))
     fields = [hip.SpinorField(X, 8, 2, data=big[n * per:(n + 1) * per]) for n in range(nev)]
-    ms, pm = [], []
-    for r in range(15):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    pm = []
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(15)]
+    for e0, e1 in ev:                       # queued back to back: the host-side descriptor build stays off the event pairs
         loop.zero_()
         e0.record()
         hip.performLoopContractionBatched(loop, fields, fields, sig)
         e1.record()
-        torch.cuda.synchronize()
-        if r >= 3:
-            ms.append(e0.elapsed_time(e1))
+    torch.cuda.synchronize()
+    ms = [e0.elapsed_time(e1) for e0, e1 in ev[3:]]
     for r in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
