@@ -311,6 +311,17 @@ def forced_full_size_worker(rank, world, port, X, nev, force, backend):
         assert em < 1e-12, ("forced partition, momentum space", em)
         del pos
     os.environ.pop("MUGIQ_HIP_HALO_AHEAD", None)
+    # a second compute on the SAME loop object (position space only): pooled halo buffers, per-block events and link fields are reused
+    prm = hip.MugiqLoopParam(gauge=g_part, calcType=hip.LOOP_CALC_TYPE_OPT_KERNEL).set_displace_entry_string(ENTRIES_CFG2)
+    loop = hip.Loop_Mugiq(prm, f, sg, comm)
+    loop.computeCoarseLoop()
+    first = loop.dataPos_d.clone()
+    loop.computeCoarseLoop()
+    assert torch.equal(loop.dataPos_d, first), "second compute on the same loop object differs"
+    e = float((first - ref_pos).abs().max()) / scale
+    assert e < 1e-13, ("forced partition, no projection", e)
+    loop.close()
+    del first
     # the reference's own sequence (BASIC: one face exchange per step and eigenvector) on a subset
     sub = "+z:1,2;-t:1;+x:1"
     b_pos, b_mom, _, _ = run(g_part, comm, hip.LOOP_CALC_TYPE_BASIC_KERNEL, sub, 2)
