@@ -34,7 +34,10 @@ loop = torch.zeros(16 * V, dtype=torch.complex128 if a.precision == 8 else torch
 variants = ["%s,%s,%s,%s" % v for v in itertools.product(a.blocks.split(","), a.depths.split(","), a.nts.split(","), a.swz.split(","))]
 times = {v: [] for v in variants}
 alg = V * (a.nev * 24 * a.precision + 32 * a.precision)
+# launches queued back to back per round (the host runs ahead of the device): with a synchronisation after every launch the time Python
+# spends building the field descriptors of a call would sit between its two events
 for r in range(a.rounds + 1):
+    evs = []
     for v in variants:
         os.environ["MUGIQ_HIP_CONTRACT_TUNE"] = v
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -42,8 +45,10 @@ for r in range(a.rounds + 1):
         e0.record()
         hip.performLoopContractionBatched(loop, fields, fields, sig)
         e1.record()
-        torch.cuda.synchronize()
-        if r > 0:
+        evs.append((v, e0, e1))
+    torch.cuda.synchronize()
+    if r > 0:
+        for v, e0, e1 in evs:
             times[v].append(e0.elapsed_time(e1))
 # calibration: achievable streaming-read bandwidth of this device on the same 40 GB
 for nt in (0, 1):
