@@ -88,17 +88,77 @@ def parse():
     ap.add_argument("--part-lattice", type=int, nargs=4, default=None, help="LOCAL lattice of the partitioned leg")
     ap.add_argument("--part-nev", type=int, default=0)
     ap.add_argument("--part-grid", type=int, nargs=4, default=None)
+    ap.add_argument("--strong-lattice", type=int, nargs=4, default=None, help="GLOBAL lattice of the strong-scaling leg (default 48 48 48 96)")
+    ap.add_argument("--strong-grid", type=int, nargs=4, default=None)
+    ap.add_argument("--detail-file", default="", help="where the full record (every leg, per-phase times, per-kernel rooflines) goes; "
+                                                      "default gpurun_out/bench_detail_n<N>.json")
     return ap.parse_args()
 
 
 # ---- synthetic inputs (SURVEY.md section 8d) -------------------------------------------------------------------------
-def make_evecs(hip, X, nev, prec, order, device, seed, pad=0):
+def global_site_index(X, grid, coord, device):
+    """[2][volumeCB] int64: the lexicographic index in the GLOBAL lattice (X[d] * grid[d] per axis) of every local even-odd site
+    (parity, x_cb) of the rank at `coord` (QUDA's checkerboard: full index i = x + X0 (y + X1 (z + X2 t)), x_cb = i / 2, parity =
+    (x + y + z + t) & 1; the local extents are even, so the local parity is the global one)."""
+    X0, X1, X2, X3 = X
+    vcb = X0 * X1 * X2 * X3 // 2
+    i2 = 2 * torch.arange(vcb, dtype=torch.int64, device=device)
+    t = i2 // (X0 * X1 * X2)
+    z = (i2 // (X0 * X1)) % X2
+    y = (i2 // X0) % X1
+    x0 = i2 % X0
+    G = [X[d] * grid[d] for d in range(4)]
+    out = []
+    for par in range(2):
+        x = x0 + ((y + z + t + par) & 1)
+        gx, gy, gz, gt = x + coord[0] * X0, y + coord[1] * X1, z + coord[2] * X2, t + coord[3] * X3
+        out.append(gx + G[0] * (gy + G[1] * (gz + G[2] * gt)))
+    return torch.stack(out)
+
+
+def _i64(x):
+    """a Python integer wrapped to the signed 64-bit range (what int64 tensor arithmetic does on the device)"""
+    x &= (1 << 64) - 1
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def _mix64(h):
+    """splitmix64-style avalanche on int64 tensors (two's-complement wrap-around; the arithmetic shift only smears sign bits
+    into positions that the following multiply scrambles again)"""
+    h = (h ^ (h >> 30)) * (-4658895280553007687)        # 0xBF58476D1CE4E5B9
+    h = (h ^ (h >> 27)) * (-7723592293110705685)        # 0x94D049BB133111EB
+    return h ^ (h >> 31)
+
+
+def _hash_complex(key):
+    """complex128 with real and imaginary parts uniform in [-0.5, 0.5): a pure function of the int64 `key`"""
+    h = _mix64(key)
+    re = ((h >> 8) & 0xFFFFF).to(torch.float64) * (1.0 / 1048576.0) - 0.5
+    im = ((h >> 32) & 0xFFFFF).to(torch.float64) * (1.0 / 1048576.0) - 0.5
+    return torch.complex(re, im)
+
+
+def make_evecs(hip, X, nev, prec, order, device, seed, pad=0, gidx=None, gvol=None):
     """N_ev synthetic eigenvectors in one HBM allocation (native layout, Stride() = volumeCB + pad), each unit-norm
-    (the pad sites carry random numbers too; they are never addressed)."""
+    (the pad sites carry random numbers too; they are never addressed).
+    gidx given (global_site_index): every component is a pure function of (seed, eigenvector, GLOBAL site, spin-colour), scaled
+    by 1 / sqrt(12 * gvol) -- the same global field on any process grid, which is what lets a partitioned run be compared with
+    the one-GPU run of the same job (FLOAT2, no pad)."""
     vcb = int(np.prod(X)) // 2
     per = 2 * 12 * (vcb + pad)
     cdt = torch.complex128 if prec == 8 else torch.complex64
     big = torch.empty(nev * per, dtype=cdt, device=device)
+    if gidx is not None:
+        assert order == 2 and pad == 0
+        base = (gidx.view(2, 1, vcb) * 12 + torch.arange(12, dtype=torch.int64, device=device).view(1, 12, 1)).reshape(-1)   # native FLOAT2: [parity][k][x_cb]
+        scale = float(np.sqrt(0.5 / gvol))                 # |uniform(-.5,.5) + i uniform(-.5,.5)|^2 averages 1/6; 12 * gvol components: global norm ~ 1
+        fields = []
+        for n in range(nev):
+            v = big[n * per:(n + 1) * per]
+            v.copy_((_hash_complex(base + _i64((seed * 1000003 + n) * 6364136223846793005)) * scale).to(cdt))
+            fields.append(hip.SpinorField(X, prec, order, data=v))
+        del base
+        return big, fields
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     fields = []
@@ -114,13 +174,19 @@ def make_evecs(hip, X, nev, prec, order, device, seed, pad=0):
     return big, fields
 
 
-def random_su3_eo(X, device, seed):
+def random_su3_eo(X, device, seed, gidx=None):
     """Random SU(3) links of the local lattice, [4 dir][2 parity * volumeCB][3][3] complex128 on the device
-    (Gram-Schmidt on rows of Gaussian matrices, third row = conj cross product => det 1)."""
+    (Gram-Schmidt on rows of random matrices, third row = conj cross product => det 1).  gidx given: the matrix is a pure function
+    of (seed, direction, GLOBAL site) -- the same global gauge field on any process grid."""
     vcb = int(np.prod(X)) // 2
-    gen = torch.Generator(device=device).manual_seed(seed)
-    m = torch.complex(torch.randn(4 * 2 * vcb, 2, 3, dtype=torch.float64, device=device, generator=gen),
-                      torch.randn(4 * 2 * vcb, 2, 3, dtype=torch.float64, device=device, generator=gen))
+    if gidx is not None:
+        key = ((torch.arange(4, dtype=torch.int64, device=device).view(4, 1) * (1 << 40) + gidx.reshape(1, -1)).reshape(-1, 1) * 6
+               + torch.arange(6, dtype=torch.int64, device=device).view(1, 6)) + _i64(seed * 6364136223846793005)
+        m = _hash_complex(key).reshape(4 * 2 * vcb, 2, 3)
+    else:
+        gen = torch.Generator(device=device).manual_seed(seed)
+        m = torch.complex(torch.randn(4 * 2 * vcb, 2, 3, dtype=torch.float64, device=device, generator=gen),
+                          torch.randn(4 * 2 * vcb, 2, 3, dtype=torch.float64, device=device, generator=gen))
     r0 = m[:, 0] / torch.linalg.vector_norm(m[:, 0], dim=-1, keepdim=True)
     r1 = m[:, 1] - (r0.conj() * m[:, 1]).sum(-1, keepdim=True) * r0
     r1 = r1 / torch.linalg.vector_norm(r1, dim=-1, keepdim=True)
@@ -128,12 +194,12 @@ def random_su3_eo(X, device, seed):
     return torch.stack([r0, r1, r2], dim=1).reshape(4, 2 * vcb, 3, 3)
 
 
-def make_gauge(hip, X, prec, device, seed, comm=None):
+def make_gauge(hip, X, prec, device, seed, comm=None, gidx=None):
     """The border-extended device gauge field.  One process: written in place (periodic, no border).  With a process
     grid: through Displace's setup path -- host QDP links of the local lattice -> mugiq_hip_create_extended_gauge,
     borders from the neighbours (lib/displace.cpp:104-134)."""
     vcb = int(np.prod(X)) // 2
-    u = random_su3_eo(X, device, seed)
+    u = random_su3_eo(X, device, seed, gidx)
     if comm is None:
         g = hip.GaugeField(X, (0, 0, 0, 0), prec)
         q = u.reshape(4, 2, vcb, 9).permute(1, 0, 3, 2).contiguous()          # [parity][dir][row*3+col][x_cb]
@@ -187,6 +253,7 @@ def cpu_baseline(fields, sigmas, X, prec, order, budget_s):
     sites_per_s = passes * 2 * S / el
     return {"value": sites_per_s, "unit": "sites/s", "cores": threads, "kind": "port",
             "host_GBps": sites_per_s * nev * 24 * prec / 1e9,
+            "sample_short": "%d sites x %d eigenvectors of the bench fields, %d passes in %.1f s, oracle/mugiq_oracle.c + OpenMP" % (2 * S, nev, passes, el),
             "sample": "%d sites x %d eigenvectors (first %d checkerboard sites of each parity of the bench fields = %d sites per "
                       "thread, pages first-touched by the reading threads), %d passes in %.1f s, oracle/mugiq_oracle.c with OpenMP (threads = the "
                       "CPUs this job may use: affinity mask capped by the cgroup quota; the host has %d hardware threads), chunks of "
@@ -275,16 +342,28 @@ def phase_sum(phases, kind, entry=None):
 
 
 # ---- extra legs ----------------------------------------------------------------------------------------------------------
-def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backend="nccl", fields=None, gauge=None):
+def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backend="nccl", fields=None, gauge=None, hashed=False):
     """The configs[2] job through the driver's OPT plan: ultra-local + 8 entries x lengths 1..3 (25 slots), then the
-    momentum projection onto p^2 <= p2max.  Returns the record with per-phase device times (best repetition)."""
+    momentum projection onto p^2 <= p2max.  Returns the record with per-phase device times (best repetition) and, under "_mom",
+    the gathered momentum-space loops [Nmom][nLoop][16][totT] of that repetition (popped by the callers before anything is printed).
+    hashed: eigenvectors and links are functions of the GLOBAL site (make_evecs / random_su3_eo with gidx), so that the result
+    does not depend on the process grid."""
     V = int(np.prod(X))
     B = prec
     multi = comm is not None and world > 1
+    gidx = None
+    if hashed:
+        grid, coord = (comm.grid, comm.coord) if comm is not None else ((1, 1, 1, 1), (0, 0, 0, 0))
+        gidx = global_site_index(X, grid, coord, device)
+        gvol = V * int(np.prod(grid))
     if fields is None:
-        _, fields = make_evecs(hip, X, nev, prec, 2, device, seed=4242 + (comm.rank if comm else 0))
+        if hashed:
+            _, fields = make_evecs(hip, X, nev, prec, 2, device, seed=4242, gidx=gidx, gvol=gvol)
+        else:
+            _, fields = make_evecs(hip, X, nev, prec, 2, device, seed=4242 + (comm.rank if comm else 0))
     if gauge is None:
-        gauge = make_gauge(hip, X, prec, device, 20240501 + (comm.rank if comm else 0), comm)
+        gauge = make_gauge(hip, X, prec, device, 20240501 + (0 if hashed else (comm.rank if comm else 0)), comm, gidx)
+    del gidx
     moms = momenta_p2_le(p2max)
     sig = 0.01 + 0.002 * np.arange(nev)
     best = None
@@ -314,7 +393,8 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
         rec = {"seconds": el, "phases": loop.phases(), "nLoop": loop.nLoop, "carrier": loop.ultraLocalCarrier(),
                "derived": [loop.derivedFrom(i) for i in range(loop.nDispEntries)],
                "entries": [loop.entry(i) for i in range(loop.nDispEntries)],
-               "device_bytes_in_use": int(total_b - free_b), "create_seconds": create_s}      # eigenvectors + links + loop buffers + the driver's scratch / halo pool
+               "device_bytes_in_use": int(total_b - free_b), "create_seconds": create_s,      # eigenvectors + links + loop buffers + the driver's scratch / halo pool
+               "mom": loop.dataMom_global()}
         loop.close()
         if r > 0 and (best is None or el < best["seconds"]):
             best = rec
@@ -325,7 +405,7 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
     ent_flops = V * nev * nslot * (36 + 48) * 8.0                               # SU(3) x spinor + colour-traced outer product, complex FMAs
     out = {"seconds": best["seconds"], "sites_per_s_all_slots": world * V / best["seconds"], "n_loop_slots": best["nLoop"],
            "entries_reflected": sum(1 for d in best["derived"] if d >= 0), "device_bytes_in_use": best["device_bytes_in_use"],
-           "create_seconds": best["create_seconds"],
+           "create_seconds": best["create_seconds"], "_mom": best["mom"],
            "roofline": {}}
     names = ["x", "y", "z", "t"]
     for i, e in enumerate(best["entries"]):
@@ -398,9 +478,18 @@ def cfg2_inputs(hip, device, nev):
     return _CFG2_INPUTS["fields"]
 
 
+def max_rel_diff(a, b):
+    """max |a - b| / max |b| over the gathered momentum-space loops of two runs of the same job"""
+    return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+
+PARITY_TOL = 1e-12        # north_star: loop traces within 1e-12 in fp64
+
+
 def extra_displaced(hip, device, nev=400):
     X = (48, 48, 24, 24)
     out = displaced_job(hip, device, X, nev, 8, None, 1, fields=cfg2_inputs(hip, device, nev))
+    _CFG2_INPUTS["mom_unpartitioned"] = out.pop("_mom")          # 19 MB on the host: what the forced-partition leg must reproduce
     out["workload"] = "48x48x24x24 fp64 N_ev=%d (configs[2] per-GPU lattice%s), entries %s, momentum projection p^2<=9, driver OPT plan" % (
         nev, "" if nev == 400 else ", N_ev reduced from 400", ENTRIES_CFG2)
     return out
@@ -417,6 +506,12 @@ def extra_forced(hip, device, nev=400, emulate_GBps=0.0):
     comm = hip.GridComm((1, 1, 1, 1), device=device, force_partitioned=(0, 0, 1, 1))
     gauge = make_gauge(hip, X, 8, device, 20240501, comm)
     out = displaced_job(hip, device, X, nev, 8, comm, 1, reps=1, fields=fields, gauge=gauge)
+    mom = out.pop("_mom")
+    ref = _CFG2_INPUTS.get("mom_unpartitioned")
+    if ref is not None:
+        # same eigenvectors, same links (seed), same momenta: the partitioned code path must give the unpartitioned numbers
+        out["max_rel_diff_forced_vs_unpartitioned"] = max_rel_diff(mom, ref)
+        out["parity_ok"] = bool(out["max_rel_diff_forced_vs_unpartitioned"] < PARITY_TOL)
     out["workload"] = "48x48x24x24 fp64 N_ev=%d, z and t FORCED-partitioned on one rank (self-neighbour: device copies, no xGMI), " \
                       "entries %s, momentum projection p^2<=9, driver OPT plan, halos posted ahead" % (nev, ENTRIES_CFG2)
     out["forced_partition"] = [0, 0, 1, 1]
@@ -425,6 +520,10 @@ def extra_forced(hip, device, nev=400, emulate_GBps=0.0):
         # hides and what it does not when the halo takes as long as it would between GPUs
         comm2 = hip.GridComm((1, 1, 1, 1), device=device, force_partitioned=(0, 0, 1, 1), emulate_link_GBps=emulate_GBps)
         emu = displaced_job(hip, device, X, nev, 8, comm2, 1, reps=1, fields=fields, gauge=gauge)
+        emom = emu.pop("_mom")
+        if ref is not None:
+            out["max_rel_diff_emulated_vs_unpartitioned"] = max_rel_diff(emom, ref)
+            out["parity_ok"] = bool(out.get("parity_ok", True) and out["max_rel_diff_emulated_vs_unpartitioned"] < PARITY_TOL)
         h = emu.get("halo", {})
         out["emulated_link"] = {"GBps_per_link": emulate_GBps, "seconds": emu["seconds"], "halo_transfer_ms": h.get("transfer_ms"),
                                 "halo_wait_ms_not_hidden": h.get("wait_ms_not_hidden"), "phase_ms": emu["phase_ms"],
@@ -542,9 +641,10 @@ def extra_partitioned(hip, device, a, world, rank, backend):
         os.environ.setdefault("MUGIQ_HIP_HALO_AHEAD", "0")
     comm = hip.GridComm(grid, device=device)
     out = displaced_job(hip, device, X, nev, 8, comm, world, reps=1, backend=backend)
+    out.pop("_mom", None)
     out["workload"] = "%dx%dx%dx%d global (local %dx%dx%dx%d on a %dx%dx%dx%d process grid) fp64 N_ev=%d, entries %s, momentum projection p^2<=9, " \
                       "driver OPT plan, halos over %s" % (tuple(X[d] * grid[d] for d in range(4)) + X + grid + (nev, ENTRIES_CFG2, backend))
-    out["grid"] = list(grid)
+    out["grid"], out["local_lattice"], out["n_ev"] = list(grid), list(X), nev
     out["halo_ahead"] = os.environ.get("MUGIQ_HIP_HALO_AHEAD", "1")
     return out
 
@@ -552,22 +652,121 @@ def extra_partitioned(hip, device, a, world, rank, backend):
 def extra_strong(hip, device, a, world, rank, backend):
     """Strong scaling of the PARTITIONED path: the SAME global problem on every N -- configs[2]'s 48^3 x 96 lattice, all 25 slots,
     momentum projection -- with as many eigenvectors as fit ONE GPU next to the position-space slots (N_ev = --strong-nev; halo
-    bytes and arithmetic both scale with N_ev, so the ratio that decides the scaling is that of the N_ev = 400 job).  N = 1 runs
-    it unpartitioned; N = 2, 4, 8 on 1x1x1x2, 1x1x1x4, 1x1x2x4 through GridComm (T first, then Z).  seconds(N = 1) / seconds(N) is
-    the speedup north_star asks about."""
+    bytes and arithmetic both scale with N_ev, so the ratio that decides the scaling is that of the N_ev = 400 job).  Eigenvectors
+    and links are functions of the GLOBAL site, so every process grid works on the same global fields.
+    N = 1 runs it unpartitioned.  N > 1: rank 0 ALONE first runs the unpartitioned job (the others wait at a barrier), keeps its
+    seconds and its momentum-space loops; then all ranks run it on 1x1x1x2, 1x1x1x4, 1x1x2x4 through GridComm (T first, then Z).
+    The line carries seconds_1gpu, seconds, speedup = seconds_1gpu / seconds -- the number north_star asks about -- and the
+    largest relative difference between the partitioned and the one-GPU loops."""
     grid = {1: (1, 1, 1, 1), 2: (1, 1, 1, 2), 4: (1, 1, 1, 4), 8: (1, 1, 2, 4)}.get(world)
-    if grid is None:
+    if a.strong_grid:
+        grid = tuple(a.strong_grid)
+    if grid is None or int(np.prod(grid)) != world:
         return {"error": "no process grid for %d ranks" % world}
-    G = (48, 48, 48, 96)
+    G = tuple(a.strong_lattice) if a.strong_lattice else (48, 48, 48, 96)
     X = tuple(G[d] // grid[d] for d in range(4))
     nev = a.strong_nev
+    one = None
+    if world > 1:
+        import torch.distributed as dist
+        if rank == 0:
+            one = displaced_job(hip, device, G, nev, 8, None, 1, reps=1, backend=backend, hashed=True)
+            torch.cuda.empty_cache()
+        dist.barrier()
     comm = hip.GridComm(grid, device=device) if world > 1 else None
-    out = displaced_job(hip, device, X, nev, 8, comm, world, reps=1, backend=backend)
-    out["workload"] = "48x48x48x96 GLOBAL lattice on %d GPU(s) (process grid %dx%dx%dx%d, local %dx%dx%dx%d) fp64 N_ev=%d, entries %s, momentum " \
-                      "projection p^2<=9, driver OPT plan%s" % ((world,) + grid + X + (nev, ENTRIES_CFG2, (", halos over " + backend) if world > 1 else ""))
-    out["grid"] = list(grid)
+    out = displaced_job(hip, device, X, nev, 8, comm, world, reps=1, backend=backend, hashed=True)
+    mom = out.pop("_mom")
+    out["workload"] = "%dx%dx%dx%d GLOBAL lattice on %d GPU(s) (process grid %dx%dx%dx%d, local %dx%dx%dx%d) fp64 N_ev=%d, entries %s, momentum " \
+                      "projection p^2<=9, driver OPT plan%s" % (G + (world,) + grid + X + (nev, ENTRIES_CFG2, (", halos over " + backend) if world > 1 else ""))
+    out["grid"], out["local_lattice"], out["n_ev"] = list(grid), list(X), nev
     out["global_sites"] = int(np.prod(G))
+    out["seconds_1gpu"] = out["seconds"] if world == 1 else None
+    if one is not None:
+        out["seconds_1gpu"] = one["seconds"]
+        out["speedup"] = one["seconds"] / out["seconds"]
+        out["max_rel_diff_vs_1gpu"] = max_rel_diff(mom, one.pop("_mom"))
+        out["parity_ok"] = bool(out["max_rel_diff_vs_1gpu"] < PARITY_TOL)
+        out["one_gpu_phase_ms"] = one["phase_ms"]
     return out
+
+
+# ---- the printed line ------------------------------------------------------------------------------------------------------
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "probe_GBps", "frac_of_probe")
+LINE_LIMIT = 3000          # characters; the driver reads the last ~8 KB of stdout
+
+
+def _r(x, digits=6):
+    """numbers to `digits` significant figures (the full-precision values are in the detail file)"""
+    if isinstance(x, (float, np.floating)):
+        return float("%.*g" % (digits, x)) if np.isfinite(x) else None      # strict JSON has no NaN / Infinity
+    if isinstance(x, (np.integer, np.bool_)):
+        return x.item()
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    return x
+
+
+def _leg_summary(rec):
+    """one short object per extra leg: its time, its slowest roofline fraction and what bounds that kernel"""
+    if "error" in rec:
+        return {"error": str(rec["error"])[:120]}
+    o = {}
+    if "seconds" in rec:
+        o["s"] = rec["seconds"]
+    elif "kernel_ms" in rec:
+        o["ms"] = rec["kernel_ms"]
+    rf = rec.get("roofline", {})
+    blocks = [rf] if "frac" in rf else [b for b in rf.values() if isinstance(b, dict) and "frac" in b]
+    if blocks:
+        heavy = max(blocks, key=lambda b: b["kernel_ms"])        # the block that takes the most time
+        o.update({"top_kernel_ms": heavy["kernel_ms"], "top_frac": heavy["frac"], "top_bound": heavy["bound"]})
+    for k in ("max_rel_diff_forced_vs_unpartitioned", "max_rel_diff_emulated_vs_unpartitioned", "max_rel_diff_vs_1gpu", "parity_ok"):
+        if k in rec:
+            o[k] = rec[k]
+    return o
+
+
+def compact_line(out, detail_path):
+    """The ONE line the driver parses: the contract's keys, the headline roofline, a trimmed cpu_baseline, the strong-scaling and
+    partitioned summaries and one short object per extra leg -- nothing else.  Everything measured is in `detail_path`."""
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data") if k in out}
+    c = out.get("config", {})
+    line["config"] = {k: c[k] for k in ("workload", "local_lattice", "n_ev", "partition") if k in c}
+    line["value_is"] = "ultra-local contraction over independent site blocks (no halo on this path); the partitioned job is under strong_scaling"
+    line["roofline"] = {k: out["roofline"].get(k) for k in _ROOF_KEYS if k in out["roofline"]}
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample_short", "max_rel_err_gpu_vs_cpu_on_sample") if k in cb}
+        line["cpu_baseline"]["sample"] = line["cpu_baseline"].pop("sample_short", str(cb.get("sample", ""))[:160])
+    for k in ("backend", "nccl_ranks", "process_grid"):
+        if k in out:
+            line[k] = out[k]
+    ss = out.get("strong_scaling")
+    if ss:
+        line["strong_scaling"] = {k: ss[k] for k in ("global_lattice", "n_ev", "grid", "seconds_1gpu", "seconds", "speedup",
+                                                     "global_sites_per_s_all_slots", "halo_wait_ms_not_hidden", "halo_GBps_per_rank",
+                                                     "max_rel_diff_vs_1gpu") if ss.get(k) is not None}
+    pt = out.get("partitioned")
+    if pt:
+        line["partitioned"] = {k: pt[k] for k in ("local_lattice", "n_ev", "seconds", "sites_per_s_all_slots", "halo_bytes_sent_per_rank",
+                                                  "halo_GBps_per_rank", "wait_ms_not_hidden") if pt.get(k) is not None}
+    also = out.get("also_measured")
+    if also:
+        line["legs"] = {k: (_leg_summary(v) if isinstance(v, dict) else str(v)[:160]) for k, v in also.items()}
+    if "parity_ok" in out:
+        line["parity_ok"] = out["parity_ok"]
+    line["detail_file"] = detail_path
+    line = _r(line)
+    text = json.dumps(line, allow_nan=False)
+    if len(text) > LINE_LIMIT:                   # never again a line the driver cannot read: drop the per-leg summaries first
+        line.pop("legs", None)
+        line["legs_dropped"] = "line over %d characters; see detail_file" % LINE_LIMIT
+        text = json.dumps(line, allow_nan=False)
+    assert "\n" not in text
+    return text
 
 
 # ---- main --------------------------------------------------------------------------------------------------------------
@@ -726,12 +925,22 @@ def main():
     printed = threading.Event()
     running = {"leg": None}
 
+    detail_path = a.detail_file or os.path.join("gpurun_out", "bench_detail_n%d.json" % world)
+
     def emit():
         with lock:
             if not printed.is_set():
                 printed.set()
                 if rank == 0:
-                    print(json.dumps(out), flush=True)
+                    try:
+                        os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+                        with open(detail_path, "w") as f:
+                            json.dump(out, f, indent=1)
+                        where = detail_path
+                    except OSError as e:
+                        where = "not written: %s" % e
+                    sys.stdout.write(compact_line(out, where) + "\n")       # the LAST stdout line, and the only one starting with {"metric"
+                    sys.stdout.flush()
 
     if not a.no_extra:
         del fields, big, loop
@@ -742,8 +951,8 @@ def main():
                  ("strong_scaling_displaced_loops", "strong", lambda: extra_strong(hip, device, a, world, rank, backend)),
                  ("mg_coarse_loop", "mg", lambda: extra_mg(hip, device)),
                  ("cfg3_mixed_precision_ultra_local", "cfg3", lambda: extra_cfg3(hip, device))] if world == 1 else
-                [("partitioned_displaced_loops", "partitioned", lambda: extra_partitioned(hip, device, a, world, rank, backend)),
-                 ("strong_scaling_displaced_loops", "strong", lambda: extra_strong(hip, device, a, world, rank, backend))])
+                [("strong_scaling_displaced_loops", "strong", lambda: extra_strong(hip, device, a, world, rank, backend)),     # the speedup first
+                 ("partitioned_displaced_loops", "partitioned", lambda: extra_partitioned(hip, device, a, world, rank, backend))])
         also = {}
         out["also_measured"] = also
 
@@ -778,23 +987,36 @@ def main():
         dog.cancel()
         sd = also.get("strong_scaling_displaced_loops")
         if sd and "error" not in sd:
-            # the same global problem at every N: seconds(N = 1) / seconds(N) is the speedup of the partitioned path
-            out["strong_scaling"] = {"workload": sd["workload"], "seconds": sd["seconds"], "global_sites_per_s_all_slots": sd["sites_per_s_all_slots"],
-                                     "halo_wait_ms_not_hidden": sd.get("halo", {}).get("wait_ms_not_hidden")}
+            # the same global problem at every N: seconds_1gpu / seconds is the speedup of the partitioned path
+            h = sd.get("halo", {})
+            G = [sd["grid"][d] * X_ for d, X_ in enumerate(sd["local_lattice"])]
+            out["strong_scaling"] = {"workload": sd["workload"], "global_lattice": G, "n_ev": a.strong_nev, "grid": sd["grid"],
+                                     "seconds_1gpu": sd.get("seconds_1gpu"), "seconds": sd["seconds"], "speedup": sd.get("speedup", 1.0 if world == 1 else None),
+                                     "global_sites_per_s_all_slots": sd["sites_per_s_all_slots"],
+                                     "halo_wait_ms_not_hidden": h.get("wait_ms_not_hidden"), "halo_GBps_per_rank": h.get("GBps_per_rank"),
+                                     "max_rel_diff_vs_1gpu": sd.get("max_rel_diff_vs_1gpu")}
         pd = also.get("partitioned_displaced_loops")
         if world > 1 and pd and "error" not in pd:
             # the partitioned configs[2] job at the top level: what a scaling curve of THIS path would be drawn from
             h = pd.get("halo", {})
             out["process_grid"] = pd.get("grid")
-            out["partitioned"] = {"workload": pd["workload"], "seconds": pd["seconds"], "sites_per_s_all_slots": pd["sites_per_s_all_slots"],
+            out["partitioned"] = {"workload": pd["workload"], "local_lattice": pd.get("local_lattice"), "n_ev": pd.get("n_ev"),
+                                  "seconds": pd["seconds"], "sites_per_s_all_slots": pd["sites_per_s_all_slots"],
                                   "halo_bytes_sent_per_rank": h.get("bytes_sent_per_rank"), "halo_GBps_per_rank": h.get("GBps_per_rank"),
                                   "wait_ms_not_hidden": h.get("wait_ms_not_hidden")}
+        checks = [v["parity_ok"] for v in also.values() if isinstance(v, dict) and "parity_ok" in v]
+        if checks:
+            out["parity_ok"] = bool(all(checks))
     emit()
     if dist is not None:
         try:
             dist.destroy_process_group()
         except Exception:
             pass
+    if out.get("parity_ok") is False:
+        # a partitioned run that does not reproduce the unpartitioned numbers is a failure of the product, not a footnote
+        sys.stderr.write("bench.py: a partitioned leg differs from its unpartitioned reference by more than %g (see %s)\n" % (PARITY_TOL, detail_path))
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

@@ -390,6 +390,7 @@ static int reserve_plan_buffers(MugiqHipLoop *lp) {
   int st = plan_opt(lp, ahead);
   if (st) return st;
   const size_t fieldB = (size_t)24 * lp->volumeCB * lp->cplxBytes();  // a FLOAT2 pad-0 path-link field
+  bool anyAhead = false;
   for (int id = 0; id < lp->nDispEntries; id++) {
     if (!ahead[id]) continue;
     const size_t faceB = (size_t)24 * (lp->volumeCB / lp->localL[lp->dispDir[id]]) * lp->cplxBytes();
@@ -397,7 +398,17 @@ static int reserve_plan_buffers(MugiqHipLoop *lp) {
       if ((st = pool_reserve(lp, fieldB))) return st;  // E_0 .. E_stop, held until the entry has run
     if ((st = pool_reserve(lp, faceB)) || (st = pool_reserve(lp, faceB))) return st;
     if ((st = pool_reserve(lp, halo_bytes(lp, id))) || (st = pool_reserve(lp, halo_bytes(lp, id)))) return st;
+    anyAhead = true;
   }
+  // the entry that runs before the halos are posted keeps its link fields out of the pool until the compute ends (see
+  // mugiq_hip_loop_compute): they come on top of what the posted entries hold
+  if (anyAhead)
+    for (int id = 0; id < lp->nDispEntries; id++)
+      if (lp->derivedFrom[id] < 0 && !lp->commDim[lp->dispDir[id]]) {
+        for (int k = 0; k <= lp->dispStop[id]; k++)
+          if ((st = pool_reserve(lp, fieldB))) return st;
+        break;
+      }
   return MUGIQ_HIP_SUCCESS;
 }
 
@@ -1215,7 +1226,7 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
     pendingBoundary.clear();
     return MUGIQ_HIP_SUCCESS;
   };
-  auto run_one = [&](int id) -> int {
+  auto run_one = [&](int id, bool holdScratch = false) -> int {
     if (id == -1 && !basic && lp->carryUltra && lp->ultraCarried) return MUGIQ_HIP_SUCCESS;  // produced by a displaced entry's pass
     if (id >= 0 && !basic && lp->momReflect && lp->derivedFrom[id] >= 0) {   // derived in momentum space; position space on request
       lp->posReflectPending = true;
@@ -1265,7 +1276,15 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
       } else st = entry_fused(lp, id, slot0);
       // No host synchronisation between entries: every user of this entry's scratch is ordered on lp->stream (the halo
       // stream's part was waited for by the boundary kernels), so the next entry may take the buffers over at once.
-      free_scratch(lp);
+      // The exception is the entry that runs BEFORE the halos are posted: the pack and halo streams start from an event
+      // recorded ahead of it, so a buffer it hands back could be given to prepare_halo as gsend / grecv and be written by the
+      // pack kernels while this entry's kernels still read it.  Its scratch stays out of the pool until the compute ends.
+      if (holdScratch) {
+        for (void *q : lp->scratch) lp->held.push_back(q);
+        lp->scratch.clear();
+      } else {
+        free_scratch(lp);
+      }
     }
     phase_end(lp, ph, lp->stream);
     return st;
@@ -1292,7 +1311,7 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
     phase_end(lp, phHalo, lp->commStream);
     return MUGIQ_HIP_SUCCESS;
   };
-  if (earlyEntry >= 0) st = run_one(earlyEntry);
+  if (earlyEntry >= 0) st = run_one(earlyEntry, postHalos);
   if (!st && postHalos) st = post_halos();
   for (int id : order) {
     if (st) break;
@@ -1310,6 +1329,7 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
   // hand the buffers of the posted halos back (their transfers were waited for by the entries that used them; after an
   // error drain the halo stream first)
   if (!lp->held.empty()) {
+    if (st && lp->packStream) (void)hipStreamSynchronize(lp->packStream);
     if (st && lp->commStream) (void)hipStreamSynchronize(lp->commStream);
     for (void *p : lp->held)
       for (auto &b : lp->pool)
@@ -1321,6 +1341,7 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
   if (lp->doMomProj && (st = momentum_projection(lp))) return st;  // :517-520
   MUGIQ_CHECK_HIP(hipStreamSynchronize(lp->stream));
   if (lp->profiling) {
+    if (lp->packStream) MUGIQ_CHECK_HIP(hipStreamSynchronize(lp->packStream));  // HALO_PREPARE's end event is recorded there
     if (lp->commStream) MUGIQ_CHECK_HIP(hipStreamSynchronize(lp->commStream));
     phases_resolve(lp);
     phase_host(lp, MUGIQ_HIP_PHASE_TOTAL_WALL, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tWall0).count());

@@ -110,9 +110,12 @@ def cpu_worker(rank, world, port, grid, G=(4, 4, 4, 8), force=(0, 0, 0, 0)):
     dist.destroy_process_group()
 
 
-def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8), seed=None, force=(0, 0, 0, 0)):
+def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8), seed=None, force=(0, 0, 0, 0), case=None):
     """The C++ driver on every rank (all on cuda:0), halos and FT reduction through the comm callbacks.
-    force: axes of extent 1 on which the partitioned path is forced (MugiqHipComm.partitioned; self-neighbour)."""
+    force: axes of extent 1 on which the partitioned path is forced (MugiqHipComm.partitioned; self-neighbour).
+    case "pool_tie": stop * N_ev == the local extent of the partitioned axes, so the multi-layer halo buffers have exactly the size
+    of a path-link field, and the entry that runs before the halos are posted has the larger stop (more link fields than any
+    posted entry) -- the scratch pool must not hand that entry's fields to the pack stream while its kernels still run."""
     import torch
     from util import orc, momenta_p2_le, rel_err
     dist = _init(rank, world, port)
@@ -136,6 +139,10 @@ def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8), 
     moms = momenta_p2_le(2)
     FTSign = 1
     nev = 3
+    if case == "pool_tie":
+        nev = 4
+        disp = (["+x", "+t", "-z", "+y", "-t"], [1, 1, 1, 2, 2], [3, 2, 2, 2, 2])
+        assert all(2 * nev == G[d] // grid[d] for d in (2, 3))
     ev_lex, U_lex, sg = _global_problem(G, nev, 1234)
     cdt = np.complex128 if prec == 8 else np.complex64
     ev_lex = [v.astype(cdt).astype(np.complex128) for v in ev_lex]           # the inputs the GPU sees

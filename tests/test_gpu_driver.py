@@ -2,6 +2,7 @@
 (BASIC = the reference's launch sequence, OPT = batched + fused), momentum projection, and the
 domain-decomposed run (2 ranks sharing the one GPU of the box, gloo transport through the comm callbacks)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -606,11 +607,81 @@ def test_forced_partitioning_on_one_rank(force, G, prec, order, calc, ahead, mon
     mp.spawn(mp_workers.gpu_worker, args=(1, free_port(), (1, 1, 1, 1), prec, order, calc, G, None, force), nprocs=1, join=True)
 
 
+def test_forced_partitioning_scratch_pool_size_tie(monkeypatch):
+    """halo buffers of the posted entries exactly as large as a link field, and the entry that runs before the halos are posted
+    holds more link fields than any of them (mp_workers.gpu_worker, case "pool_tie"): the pool must not hand that entry's fields to
+    the pack stream while its kernels still read them.  Once with the default halo blocks, once with one message per entry."""
+    for blocks in (None, "1"):
+        if blocks:
+            monkeypatch.setenv("MUGIQ_HIP_HALO_BLOCKS", blocks)
+        mp.spawn(mp_workers.gpu_worker, args=(1, free_port(), (1, 1, 1, 1), 8, 2, 1, (4, 4, 8, 8), None, (0, 0, 1, 1), "pool_tie"), nprocs=1, join=True)
+
+
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
 def test_full_size_forced_partition_equals_unpartitioned(backend):
     """configs[2] per-GPU lattice 48.48.24.24 with z and t forced-partitioned (its 1x1x2x4 grid seen from one rank): all 8
     entries x lengths 1..3, OPT with halos posted ahead and not, BASIC on a subset == the unpartitioned run to 1e-13."""
     mp.spawn(mp_workers.forced_full_size_worker, args=(1, free_port(), (48, 48, 24, 24), 4, (0, 0, 1, 1), backend), nprocs=1, join=True)
+
+
+def test_configs2_full_size_nev400_forced_partition(hip, monkeypatch, record_max):
+    """BASELINE.json configs[2] AS WRITTEN for one rank of its 1x1x2x4 grid: 48.48.24.24, N_ev = 400 (102 GB of eigenvectors), all 8
+    entries x lengths 1..3, momentum projection p^2 <= 9, z and t partitioned (the rank is its own neighbour).  At this N_ev the
+    partitioned plan runs what the few-eigenvector tests never reach: 2 x 25.5 GB of halo buffers from the pool, six blocks of
+    eigenvectors per halo, messages split below 2 GiB, `soff` / ghost_vec_stride past 2^31 bytes.
+      (1) the partitioned momentum-space loops equal the unpartitioned ones (an independent path: shifts wrap inside the kernels)
+          to 1e-12 -- with reflection OFF on the partitioned side, so that all 8 entries go through the halo path;
+      (2) on the partitioned position-space loops, Gamma = 1: the lattice sum of the loop displaced by -k mu is the complex
+          conjugate of the one displaced by +k mu (two independent computations, both through halos on z and t)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_evecs, make_gauge, ENTRIES_CFG2
+    X, nev = (48, 48, 24, 24), 400
+    V = int(np.prod(X))
+    dev = torch.device("cuda", 0)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    if free_b < 230e9:
+        pytest.skip("needs ~215 GB of free HBM (%.0f GB free)" % (free_b / 1e9))
+    big, f = make_evecs(hip, X, nev, 8, 2, dev, seed=2024)
+    sg = 0.01 + 0.002 * np.arange(nev)
+    moms = momenta_p2_le(9)
+
+    def run(gauge, comm):
+        prm = hip.MugiqLoopParam(gauge=gauge, doMomProj=True, momMatrix=moms, Nmom=len(moms), FTSign=-1).set_displace_entry_string(ENTRIES_CFG2)
+        loop = hip.Loop_Mugiq(prm, f, sg, comm).setProfiling()
+        loop.computeCoarseLoop()
+        return loop
+
+    monkeypatch.delenv("MUGIQ_HIP_REFLECT", raising=False)
+    loop = run(make_gauge(hip, X, 8, dev, 77, None), None)
+    assert sum(loop.derivedFrom(i) >= 0 for i in range(8)) == 4
+    ref_mom = np.array(loop.dataMom_global())
+    loop.close()
+    del loop
+    torch.cuda.empty_cache()
+
+    monkeypatch.setenv("MUGIQ_HIP_REFLECT", "0")
+    comm = hip.GridComm((1, 1, 1, 1), device=dev, force_partitioned=(0, 0, 1, 1))
+    loop = run(make_gauge(hip, X, 8, dev, 77, comm), comm)
+    assert all(loop.derivedFrom(i) < 0 for i in range(8))
+    ph = loop.phases()
+    kinds = set(p["kind"] for p in ph)
+    assert {"halo_transfer", "entry_interior", "entry_boundary"} <= kinds, kinds
+    halo_bytes = sum(p["bytes"] for p in ph if p["kind"] == "halo_transfer")
+    # z and t entries, both signs, 3 layers of all 400 eigenvectors: 4 x 3 x 400 x (V / 24) x 192 B
+    assert halo_bytes == 4 * 3 * nev * (V // 24) * 192, halo_bytes
+    mom = np.array(loop.dataMom_global())
+    e = float(np.max(np.abs(mom - ref_mom)) / np.max(np.abs(ref_mom)))
+    record_max("configs2_nev400_forced_vs_unpartitioned_mom", e)
+    assert e < 1e-12, e
+    pos = loop.dataPos_d.view(loop.nLoop, 16, V)
+    for axis in range(4):
+        for k in range(3):
+            plus = pos[1 + 6 * axis + k, 0].sum().item()
+            minus = pos[1 + 6 * axis + 3 + k, 0].sum().item()
+            assert abs(plus - np.conj(minus)) < 1e-11 * max(abs(plus), 1e-3), (axis, k, plus, minus)
+    loop.close()
+    del pos, loop, f, big
+    torch.cuda.empty_cache()
 
 
 def test_full_size_reflected_entries_agree_with_computed_ones(hip, monkeypatch):
