@@ -364,6 +364,7 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
     if gauge is None:
         gauge = make_gauge(hip, X, prec, device, 20240501 + (0 if hashed else (comm.rank if comm else 0)), comm, gidx)
     del gidx
+    torch.cuda.empty_cache()       # the generators' temporaries go back to the device: the driver's own hipMalloc calls crawl when HBM is nearly full
     moms = momenta_p2_le(p2max)
     sig = 0.01 + 0.002 * np.arange(nev)
     best = None
