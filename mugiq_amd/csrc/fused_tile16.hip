@@ -18,9 +18,12 @@
 namespace mugiq {
 
 constexpr int kT16Cols = 16;       // lines per item (each line is held by two lanes: one per spin half)
-constexpr int kT16TJ = 4;          // positions along mu per column tile
+static int t16_tj() {              // positions along mu per column tile (MUGIQ_HIP_TILE16_TJ = 4 | 8)
+  if (const char *e = getenv("MUGIQ_HIP_TILE16_TJ")) return atoi(e) == 8 ? 8 : 4;
+  return 4;
+}
 constexpr int kT16MaxSlots = 3;
-constexpr int kT16MaxItems = 18;   // 9 waves
+constexpr int kT16MaxItems = 24;   // 12 waves
 constexpr int kT16MaxPos = 16;     // staged positions: TJ + Kmax upper bound
 constexpr int kT16Row = 12 * kT16Cols;  // elements of one staged position
 
@@ -47,6 +50,7 @@ template <typename F, typename A> struct Tile16Args {
   int numCols;    // V / X[DIR]
   int jtBegin;    // column tile: tiles along mu handled by this launch: [jtBegin, jtBegin + jtCount)
   int jtCount;
+  int tj;         // column tile: positions along mu per tile
   int npc;        // computed positions per tile (column: TJ; row: 2 m)
   int np;         // staged positions per tile (column: TJ + kmax; row: 2 m)
   int m;          // row tile: 16-entry pieces per parity
@@ -92,7 +96,7 @@ __device__ __forceinline__ void tile16_body(const Tile16Args<F, A> &a) {
   if constexpr (DIR >= 1) {
     const int jt = a.jtBegin + blk % a.jtCount;
     cc = blk / a.jtCount;
-    j0 = jt * kT16TJ;
+    j0 = jt * a.tj;
   } else {
     tileBaseX = blk * (a.m * kT16Cols);
   }
@@ -370,7 +374,7 @@ __device__ __forceinline__ void tile16_body(const Tile16Args<F, A> &a) {
 }
 
 template <typename F, typename A, int ORDER, int DIR, int SIGN, int PHL, bool GLDS>
-__global__ __launch_bounds__(64 * 9) void tile16_displaced_contract_kernel(Tile16Args<F, A> a) {
+__global__ __launch_bounds__(64 * 12) void tile16_displaced_contract_kernel(Tile16Args<F, A> a) {
   tile16_body<F, A, ORDER, DIR, SIGN, PHL, GLDS>(a);
 }
 #undef MUGIQ_T16_FETCH
@@ -398,14 +402,15 @@ static bool tile16_plan(const MugiqHipSpinorField &ev, int dir, int kmax, int pa
     p.minWaves = 2;
     return true;
   }
-  if (ev.X[dir] % kT16TJ != 0) return false;
+  const int tj = t16_tj();
+  if (ev.X[dir] % tj != 0) return false;
   if (kmax > ev.X[dir]) return false;  // the staged window wraps at most once around the lattice
-  if (kT16TJ + kmax > kT16MaxPos) return false;
+  if (tj + kmax > kT16MaxPos) return false;
   p.m = 0;
-  p.npc = kT16TJ;
-  p.np = kT16TJ + kmax;
+  p.npc = tj;
+  p.np = tj + kmax;
   p.maxSlots = kT16MaxSlots;
-  p.minWaves = 6;  // idle waves of a launch with fewer slots still stage
+  p.minWaves = 6 * tj / 4;  // idle waves of a launch with fewer slots still stage
   return true;
 }
 
@@ -427,7 +432,8 @@ bool tile16_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int pre
   // staging loads per lane with the fewest threads a launch may have (one slot)
   const int waves = std::max(p.minWaves, (p.npc + 1) / 2);
   const int phl = (p.np * kT16Row + 64 * waves - 1) / (64 * waves);
-  return phl <= 8 && (size_t)2 * 2 * precision * 8 * 64 * 9 <= 160 * 1024;
+  const int phlSel = phl <= 2 ? 2 : (phl <= 4 ? 4 : 8);
+  return phl <= 8 && (size_t)2 * 2 * precision * phlSel * 64 * waves <= 160 * 1024;  // two staging tiles (three when they fit: launch_tile16)
 }
 
 template <typename F, typename A, int ORDER> static int launch_tile16(Tile16Args<F, A> a, int dir, int sign, int minWaves, hipStream_t stream) {
@@ -508,7 +514,9 @@ int tile16_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigm
   a.strideMu = (int)strideMu;
   a.H = (int)(ev[0].volumeCB / (ev[0].X[dir] * strideMu));
   a.numCols = 2 * ev[0].volumeCB / ev[0].X[dir];
-  const int nJT = dir == 0 ? 1 : ev[0].X[dir] / kT16TJ;
+  const int tj = t16_tj();
+  a.tj = tj;
+  const int nJT = dir == 0 ? 1 : ev[0].X[dir] / tj;
   a.overwrite = (region & MUGIQ_HIP_REGION_OVERWRITE) ? 1 : 0;
   region &= 0xff;
   int kmaxAll = 0;
@@ -527,12 +535,12 @@ int tile16_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigm
     }
     a.m = plan.m;
     a.npc = plan.npc;
-    a.np = dir == 0 ? plan.np : kT16TJ + a.kmax;
+    a.np = dir == 0 ? plan.np : tj + a.kmax;
     // region 0: everything | 1: tiles whose shifted reads stay inside the local lattice | 2: tiles that read ghost layers
     a.jtBegin = 0;
     a.jtCount = nJT;
     if (region != MUGIQ_HIP_REGION_ALL && dir >= 1) {
-      const int nb = partitioned ? std::min(nJT, (a.kmax + kT16TJ - 1) / kT16TJ) : 0;  // boundary tiles
+      const int nb = partitioned ? std::min(nJT, (a.kmax + tj - 1) / tj) : 0;  // boundary tiles
       if (region == MUGIQ_HIP_REGION_INTERIOR) {
         a.jtBegin = sign == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : nb;
         a.jtCount = nJT - nb;
