@@ -1,28 +1,32 @@
-// Fused displaced contraction on the fp64 matrix pipe (fourth generation; fp64 FLOAT2 column tiles, mu = y, z, t).
+// Fused displaced contraction in an axial gauge on the fp64 matrix pipe (fourth generation; fp64 FLOAT2 column tiles,
+// mu = y, z, t, lengths 1 .. Kmax).
 //
-// Same tile as csrc/fused_tile.hip -- a workgroup owns 32 lines along mu x 4 consecutive positions and stages the 4 + Kmax
-// positions it needs global -> LDS into three rotating buffers, one barrier per eigenvector -- but the arithmetic runs as
-// chained v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction, ONE LATTICE SITE PER BLOCK.
+// (1) The gauge.  Along every line of direction mu fix g(j + 1) = g(j) U_mu(x_j), g(0) = 1 (continued past both ends of
+// the local line with the path-link products the driver has anyway: g(J + l) = g(J - 1) W_{l+1}(x_{J-1}), g(-l) = W^-_l(x_0)).
+// Then g(x) U_mu(x) g(x + mu)^dag = 1, i.e. W_k(x) psi(x + k mu) = g(x)^dag [g psi](x + k mu), and because the colour trace
+// does not see a unitary rotation of both factors
+//        sum_c conj(v(x)[be][c]) (W_k(x) v(x + k mu))[al][c]  =  sum_c conj(v'(x)[be][c]) v'(x + k mu)[al][c],   v' = g v.
+// The tile applies g ONCE per staged position and eigenvector (9 complex FMAs per spin) on the way into LDS, instead of W_k
+// once per slot: 36 (4 + Kmax)/4 + 48 Kmax complex FMAs per site where csrc/fused_tile.hip spends 84 Kmax (Kmax = 3:
+// 207 against 252), and no link field is read by the contraction any more.
 //
-//   lane maps of the instruction (tools/probes/mfma_4x4x4_layout.hip, one-hot operands):
-//     A[b][i][k] in lane 16 k + 4 b + i,   B[b][k][j] in lane 16 k + 4 b + j,   D[b][i][j] in lane 16 i + 4 b + j
-//   i.e. a result D is, as it stands, the B operand of the next product with its row index as the summation index.
+// (2) The matrix pipe.  What is left per site, slot and eigenvector is a 4 x 3 times 3 x 4 complex product -- one block of
+// v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 products per instruction, ONE LATTICE SITE PER BLOCK):
+//     lane maps (tools/probes/mfma_4x4x4_layout.hip, one-hot operands):
+//       A[b][i][k] in lane 16 k + 4 b + i,   B[b][k][j] in lane 16 k + 4 b + j,   D[b][i][j] in lane 16 i + 4 b + j
+//     accR[be][al] += VR[be][c] PR[c][al] + VI[be][c] PI[c][al]          V = v'(x) / sigma_n, P = v'(x + k mu)
+//     accI[be][al] += VR[be][c] PI[c][al] - VI[be][c] PR[c][al]          (colour index c padded 3 -> 4 with V = 0)
+// Four products of 128 flops do the 384 flops of the outer product (75 %); V and P come from LDS with ONE ds_read_b128 per
+// lane and 4-site group each (V is shared by the slots) and ARE the operands as they stand; the 4x4 colour-traced spin
+// matrices accumulate in the D registers (2 x 2 VGPRs per group and slot).
 //
-//   per site, slot and eigenvector (real 4x4 tiles; colour index padded 3 -> 4, W has zeros there):
-//     stage 1   tR[i][al] = WR[i][j] psiR[j][al] - WI[i][j] psiI[j][al]        t = W_k(x) psi(x + k mu), 4 products
-//               tI[i][al] = WI[i][j] psiR[j][al] + WR[i][j] psiI[j][al]
-//     stage 2   accR[be][al] += VR[be][i] tR[i][al] + VI[be][i] tI[i][al]      acc += conj(v(x)) (x) t, 4 products
-//               accI[be][al] += VR[be][i] tI[i][al] - VI[be][i] tR[i][al]      (V = v(x) / sigma_n)
-//   W sits in registers for the whole kernel, psi and v come from LDS with ONE ds_read_b128 per lane and 4-site group
-//   each (v is shared by the slots), the 4x4 colour-traced spin matrices accumulate in the D registers (2 x 2 VGPRs per
-//   group and slot).  8 products of 128 flops do the 672 flops of the mathematics (66 %), but the vector pipe issues
-//   nothing but two multiplies per group: 96 MFMAs against 16 LDS reads and 8 VALU instructions per wave and eigenvector,
-//   where the vector form of csrc/fused_tile.hip issues 205 VALU instructions and 18 LDS reads per wave for a third of
-//   the sites.  Measured: profiles/r04_mfma_tile.txt.
-//
-// LDS image: chunk (position pair, component) = [position & 1][32 lines] complex = 1 KiB (one global_load_lds
-// instruction), chunks 64 bytes apart from each other's bank phase (stride 1088 B): an operand read -- lanes (k | i, site,
-// spin) -> component 3 spin + colour -- then touches every bank once (no conflicts; see the bank arithmetic in DESIGN.md).
+// Tile and pipeline as csrc/fused_tile.hip: a workgroup owns 32 lines along mu x 4 consecutive positions and needs 4 + Kmax
+// staged positions; thread (position, spin, line) loads its three colours two eigenvectors ahead into registers, rotates
+// them with its g (in registers for the whole kernel) and commits v' to the other LDS buffer while the products of the
+// current eigenvector run; one LDS-only barrier per eigenvector.
+// LDS image: chunk (position pair, component) = [position & 1][32 lines] complex = 1 KiB, chunks 64 bytes apart in bank
+// phase (stride 1088 B): an operand read -- lanes (colour, site, spin) -> component 3 spin + colour -- touches every bank
+// once.  Measurements, and the form with W_k applied on the matrix pipe that this one replaces: profiles/r04_mfma_tile.txt.
 #include "internal.h"
 
 #include <algorithm>
@@ -32,13 +36,16 @@
 
 namespace mugiq {
 
-constexpr int kMT_TJ = 4;         // positions along mu per workgroup
-constexpr int kMT_Cols = 32;      // lines per workgroup
-// wave w: position w & 3, lines 4 G (w >> 2) .. + 4 G - 1 (G groups of 4 sites): G = 4 -> 8 waves, G = 2 -> 16 waves
-constexpr int kMT_MaxSlots = 4;   // 3 displaced slots + the ultra-local loop riding along (k = 0, W = 1)
-constexpr int kMT_Pairs = 4;      // staged positions (TJ + Kmax <= 8) in pairs
+// Tile geometries (TJ positions along mu x LN lines per workgroup; 16 waves = 1024 threads each):
+//   TJ =  4, LN = 32: 128 sites, 4 + Kmax <=  8 staged positions, 1 + Kmax/4  units requested per site (the tile of csrc/fused_tile.hip)
+//   TJ =  8, LN = 16: 128 sites, 8 + Kmax <= 16 staged positions, 1 + Kmax/8
+//   TJ = 12, LN = 16: 192 sites, 12 + Kmax <= 16 staged positions, 1 + Kmax/12
+// 4-site groups: TJ LN / 4, an equal share per wave (2 | 2 | 3), group -> (position, 4 consecutive lines).
+constexpr int kMT_Waves = 16;
+constexpr int kMT_MaxSlots = 4;   // 3 displaced slots + the ultra-local loop riding along (k = 0)
 constexpr int kMT_Chunk = 68;     // complex elements per chunk: 64 + 4 of bank phase
-constexpr int kMT_BufElems = kMT_Pairs * 12 * kMT_Chunk;
+constexpr int kMT_Chunks = 4 * 12;  // chunks of a tile buffer: 64 / LN positions each, 12 components, <= 4 * 64 / LN staged positions
+constexpr int kMT_BufElems = kMT_Chunks * kMT_Chunk;
 
 struct MTileArgs {
   Cplx<double> *out[kMT_MaxSlots];
@@ -49,7 +56,7 @@ struct MTileArgs {
   int volumeCB;
   int stride;
   int64_t parity_offset;
-  const double *E[kMT_MaxSlots];  // path links W_k of every slot; NULL = the identity (k = 0)
+  const Cplx<double> *G;  // the axial gauge: [9][J + kmax][numCols] (sign +: position j | sign -: position j + kmax)
   int k[kMT_MaxSlots];
   int kmax;
   int partitioned;
@@ -65,19 +72,107 @@ struct MTileArgs {
   int overwrite;  // store instead of accumulate (MUGIQ_HIP_REGION_OVERWRITE)
 };
 
+// line `cid` of direction mu: parity and checkerboard index of its j = 0 site
+__host__ __device__ inline void mt_line(int cid, int H, int strideMu, int J, int &p0, int &base) {
+  const int colsPerParity = H * strideMu;
+  p0 = cid / colsPerParity;
+  const int rem = cid - p0 * colsPerParity;
+  const int hi = rem / strideMu;
+  const int lo = rem - hi * strideMu;
+  base = hi * (J * strideMu) + lo;
+}
+
+// ---- the axial gauge of one (direction, sign) from the path-link fields E_k = W_k (FLOAT2, pad 0; component 3 j + i of
+// E_k(x) is W_k(x)[i][j]): one thread per line, sequential along the line
+struct AxialArgs {
+  Cplx<double> *G;
+  const Cplx<double> *E[4];  // E_1 .. E_kmax
+  int kmax, sign, J, strideMu, H, numCols, volumeCB;
+};
+__device__ inline void mt_load_w(Cplx<double> w[9], const Cplx<double> *E, int par, int x_cb, int volumeCB) {
+  const Cplx<double> *e = E + (int64_t)par * 12 * volumeCB + x_cb;
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int i = 0; i < 3; i++) w[i * 3 + j] = e[(int64_t)(j * 3 + i) * volumeCB];
+}
+// r = x y (DAG: x y^dag)
+template <bool DAG> __device__ inline void mt_mul3(Cplx<double> r[9], const Cplx<double> x[9], const Cplx<double> y[9]) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      Cplx<double> s{0.0, 0.0};
+#pragma unroll
+      for (int m = 0; m < 3; m++) {
+        if (DAG) cmadd(s, x[i * 3 + m], Cplx<double>{y[j * 3 + m].re, -y[j * 3 + m].im});
+        else cmadd(s, x[i * 3 + m], y[m * 3 + j]);
+      }
+      r[i * 3 + j] = s;
+    }
+}
+__global__ __launch_bounds__(64) void axial_gauge_kernel(AxialArgs a) {
+  const int cid = blockIdx.x * 64 + threadIdx.x;
+  if (cid >= a.numCols) return;
+  int p0, base;
+  mt_line(cid, a.H, a.strideMu, a.J, p0, base);
+  const int Jext = a.J + a.kmax;
+  auto store = [&](int jext, const Cplx<double> g[9]) {
+#pragma unroll
+    for (int c = 0; c < 9; c++) a.G[((int64_t)c * Jext + jext) * a.numCols + cid] = g[c];
+  };
+  Cplx<double> g[9], w[9], t[9];
+#pragma unroll
+  for (int c = 0; c < 9; c++) g[c] = Cplx<double>{c % 4 == 0 ? 1.0 : 0.0, 0.0};
+  const int off = a.sign == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : a.kmax;
+  if (a.sign == MUGIQ_HIP_DISP_SIGN_MINUS) {  // g(-l) = W^-_l(x_0)
+    for (int l = 1; l <= a.kmax; l++) {
+      mt_load_w(w, a.E[l - 1], p0, base, a.volumeCB);
+      store(a.kmax - l, w);
+    }
+  }
+  for (int j = 0; j < a.J; j++) {
+    const int par = p0 ^ (j & 1), x_cb = base + j * a.strideMu;
+    if (a.sign == MUGIQ_HIP_DISP_SIGN_MINUS && j > 0) {  // g(j) = g(j - 1) W^-_1(x_j)^dag      (W^-_1(x) = U(x - mu)^dag)
+      mt_load_w(w, a.E[0], par, x_cb, a.volumeCB);
+      mt_mul3<true>(t, g, w);
+#pragma unroll
+      for (int c = 0; c < 9; c++) g[c] = t[c];
+    }
+    store(j + off, g);
+    if (a.sign == MUGIQ_HIP_DISP_SIGN_PLUS) {
+      if (j == a.J - 1) {  // g(J + l) = g(J - 1) W_{l+1}(x_{J-1})
+        for (int l = 0; l < a.kmax; l++) {
+          mt_load_w(w, a.E[l], par, x_cb, a.volumeCB);
+          mt_mul3<false>(t, g, w);
+          store(a.J + l, t);
+        }
+      } else {  // g(j + 1) = g(j) W_1(x_j)
+        mt_load_w(w, a.E[0], par, x_cb, a.volumeCB);
+        mt_mul3<false>(t, g, w);
+#pragma unroll
+        for (int c = 0; c < 9; c++) g[c] = t[c];
+      }
+    }
+  }
+}
+
 #define MUGIQ_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f64_4x4x4f64(a_, b_, c_, 0, 0, 0)
 #ifndef MUGIQ_MT_EXPERIMENT
-#define MUGIQ_MT_EXPERIMENT 0  // probe builds only (tools/probes): 1 no global loads in the steps, 2 + no barrier, 3 + no LDS reads
+#define MUGIQ_MT_EXPERIMENT 0  // probe builds only (tools/probes/build_exp.sh): 1 no global loads in the steps, 2 + no barrier, 3 + no rotation / commit, 4 staging only (no products)
 #endif
 
-template <int DIR, int SIGN, int NS, int G, bool HOIST>
-__global__ __launch_bounds__(64 * 32 / G) void mfma_tile_displaced_contract_kernel(MTileArgs a) {
-  constexpr int kMT_Groups = G, kMT_Waves = 32 / G;
-  constexpr int kMT_PerWave = kMT_Pairs * 12 / kMT_Waves;  // chunks a wave stages per eigenvector (6 | 3)
+template <int DIR, int SIGN, int NS, int TJ, int LN>
+__global__ __launch_bounds__(64 * kMT_Waves) void mfma_tile_displaced_contract_kernel(MTileArgs a) {
+  constexpr int kMT_TJ = TJ, kMT_Cols = LN;
+  constexpr int kPPC = 64 / LN;                              // positions per chunk (2 | 4)
+  constexpr int kMT_Groups = TJ * LN / 4 / kMT_Waves;        // 4-site groups per wave
+  constexpr int kGP = LN / 4;                                // groups per position
+  constexpr int kSites = TJ * LN;
   extern __shared__ __align__(16) unsigned char smem[];
-  Cplx<double> *tileBase = reinterpret_cast<Cplx<double> *>(smem);  // 3 x [pair][12][68]
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  Cplx<double> *tileBase = reinterpret_cast<Cplx<double> *>(smem);  // 2 x [pair][12][68]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int J = a.X[DIR];
   const int NP = kMT_TJ + a.kmax;
 
@@ -90,219 +185,202 @@ __global__ __launch_bounds__(64 * 32 / G) void mfma_tile_displaced_contract_kern
   const int cc = blk / a.jtCount;
   const int j0 = jt * kMT_TJ;
 
-  // a line of the tile: parity of its j = 0 site, x_cb of that site, index on the face (ghost layers)
-  auto line_info = [&](int c32, int &p0, int &base, int &faceIdx, bool &ok) {
-    int cid = cc * kMT_Cols + c32;
-    ok = cid < a.numCols;
-    if (!ok) cid = a.numCols - 1;  // surplus lines shadow the last one (valid addresses, result dropped)
-    const int colsPerParity = a.H * a.strideMu;
-    p0 = cid / colsPerParity;
-    const int rem = cid - p0 * colsPerParity;
-    const int hi = rem / a.strideMu;
-    const int lo = rem - hi * a.strideMu;
-    base = hi * (J * a.strideMu) + lo;
-    int c0[4];
-    get_coords(c0, base, a.X, p0);  // c0[DIR] == 0
-    faceIdx = ghost_face_index_on_face(c0, a.X, DIR);
-  };
+  // ---- staging role: thread <-> (position t / (4 LN), spin, line t % LN); three colours each
+  const int spp = LN == 32 ? wave >> 1 : wave, sspin = (t / LN) & 3, sline = t & (LN - 1);
+  const bool stages = spp < NP;  // (wave-uniform: the waves of the unused positions only compute)
 
-  // ---- staging: chunk q = wave * 6 + i <-> (pair q / 12, component q % 12); lane -> position 2 pair + (lane >> 5), line lane & 31
+  int soff = 0, cstride = a.stride;
+  bool fromGhost = false;
+  Cplx<double> g[9];
+#pragma unroll
+  for (int c = 0; c < 9; c++) g[c] = Cplx<double>{0.0, 0.0};
+  int wIdx = 0;
+  if (stages) {
+    int cid = cc * kMT_Cols + sline;
+    if (cid >= a.numCols) cid = a.numCols - 1;  // surplus lines shadow the last one (valid addresses, result dropped)
+    int p0, base;
+    mt_line(cid, a.H, a.strideMu, J, p0, base);
+    int j = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? j0 + spp : j0 - a.kmax + spp;
+    const int jext = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? j : j + a.kmax;
+    const int Jext = J + a.kmax;
+#pragma unroll
+    for (int c = 0; c < 9; c++) g[c] = a.G[((int64_t)c * Jext + jext) * a.numCols + cid];
+    const int par = p0 ^ (j & 1);
+    if ((j < 0 || j >= J) && a.partitioned) {
+      int c0[4];
+      get_coords(c0, base, a.X, p0);  // c0[DIR] == 0
+      const int faceIdx = ghost_face_index_on_face(c0, a.X, DIR);
+      const int layer = (j >= J) ? j - J : -j - 1;
+      fromGhost = true;
+      cstride = a.faceCB;
+      soff = (int)((int64_t)layer * 24 * a.faceCB + (int64_t)par * 12 * a.faceCB + (int64_t)(3 * sspin) * a.faceCB + faceIdx);
+    } else {
+      j = j < 0 ? j + J : (j >= J ? j - J : j);
+      soff = (int)((int64_t)par * a.parity_offset + (int64_t)(3 * sspin) * a.stride + base + j * a.strideMu);
+    }
+    wIdx = ((spp / kPPC) * 12 + 3 * sspin) * kMT_Chunk + (spp % kPPC) * kMT_Cols + sline;
+  }
   const Cplx<double> *ghostBase = reinterpret_cast<const Cplx<double> *>(a.ghost);
-  int soff[kMT_PerWave];
-  unsigned sghost = 0;
-  {
-    int p0, base, faceIdx;
-    bool ok;
-    line_info(lane & 31, p0, base, faceIdx, ok);
-#pragma unroll
-    for (int i = 0; i < kMT_PerWave; i++) {
-      const int q = wave * kMT_PerWave + i;
-      const int pair = q / 12, comp = q - pair * 12;
-      int pp = 2 * pair + (lane >> 5);
-      pp = pp < NP ? pp : NP - 1;  // surplus positions re-read the last one
-      int j = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? j0 + pp : j0 - a.kmax + pp;
-      const int par = p0 ^ (j & 1);
-      if ((j < 0 || j >= J) && a.partitioned) {
-        const int layer = (j >= J) ? j - J : -j - 1;
-        sghost |= 1u << i;
-        soff[i] = (int)((int64_t)layer * 24 * a.faceCB + (int64_t)par * 12 * a.faceCB + (int64_t)comp * a.faceCB + faceIdx);
-      } else {
-        j = j < 0 ? j + J : (j >= J ? j - J : j);
-        soff[i] = (int)((int64_t)par * a.parity_offset + (int64_t)comp * a.stride + base + j * a.strideMu);
-      }
-    }
-  }
 
-  // ---- arithmetic: lane = 16 hi + 4 b + lo; site b of group g = line 16 (wave >> 2) + 4 g + b at position wave & 3
+  // ---- arithmetic role: lane = 16 hi + 4 b + lo; group wave * G + gi = (position, line quad), site b = line 4 quad + b
   const int lo = lane & 3, b = (lane >> 2) & 3, hi = lane >> 4;
-  const int wpos = wave & 3, lineBase = 4 * G * (wave >> 2) + b;
-  const int ppL = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? wpos : a.kmax + wpos;
   const int compRd = 3 * lo + (hi < 2 ? hi : 2);  // component 3 spin + colour (the padding lanes hi = 3 re-read colour 2)
-  auto elemIdx = [&](int pp) { return ((pp >> 1) * 12 + compRd) * kMT_Chunk + (pp & 1) * kMT_Cols + lineBase; };
-  const int vIdx = elemIdx(ppL);
-  int pIdx[NS];
+  auto elemIdx = [&](int pp, int line) { return ((pp / kPPC) * 12 + compRd) * kMT_Chunk + (pp % kPPC) * kMT_Cols + line; };
+  int vIdx[kMT_Groups], pIdx[kMT_Groups][NS];
 #pragma unroll
-  for (int s = 0; s < NS; s++) pIdx[s] = elemIdx((SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? wpos + a.k[s] : a.kmax + wpos - a.k[s]);
-
-  // W_k(x) of every (group, slot) as the A operand of stage 1: lane (k = hi, site b, i = lo) holds W[i = lo][j = hi]
-  double WR[kMT_Groups][NS], WI[kMT_Groups][NS], nWI[kMT_Groups][NS];
+  for (int gi = 0; gi < kMT_Groups; gi++) {
+    const int gid = wave * kMT_Groups + gi, gpos = gid / kGP, gline = 4 * (gid % kGP) + b;
+    vIdx[gi] = elemIdx((SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? gpos : a.kmax + gpos, gline);
 #pragma unroll
-  for (int g = 0; g < kMT_Groups; g++) {
-    int p0, base, faceIdx;
-    bool ok;
-    line_info(lineBase + 4 * g, p0, base, faceIdx, ok);
-    const int jmine = j0 + wpos;
-    const int pmine = p0 ^ (jmine & 1), xmine = base + jmine * a.strideMu;
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-      Cplx<double> w{0.0, 0.0};
-      if (lo < 3 && hi < 3) {
-        if (a.E[s]) w = reinterpret_cast<const Cplx<double> *>(a.E[s])[(int64_t)pmine * 12 * a.volumeCB + (int64_t)(hi * 3 + lo) * a.volumeCB + xmine];
-        else w = Cplx<double>{lo == hi ? 1.0 : 0.0, 0.0};  // the carried ultra-local slot
-      }
-      WR[g][s] = w.re;
-      WI[g][s] = w.im;
-      nWI[g][s] = -w.im;
-    }
+    for (int s = 0; s < NS; s++) pIdx[gi][s] = elemIdx((SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? gpos + a.k[s] : a.kmax + gpos - a.k[s], gline);
   }
+  const double colourMask = hi < 3 ? 1.0 : 0.0;  // the padded colour of the left operand is ZERO (the right one may hold anything finite)
+
   double aR[kMT_Groups][NS], aI[kMT_Groups][NS];
 #pragma unroll
-  for (int g = 0; g < kMT_Groups; g++)
+  for (int gi = 0; gi < kMT_Groups; gi++)
 #pragma unroll
-    for (int s = 0; s < NS; s++) aR[g][s] = aI[g][s] = 0.0;
+    for (int s = 0; s < NS; s++) aR[gi][s] = aI[gi][s] = 0.0;
 
-#if defined(__HIP_DEVICE_COMPILE__)  // (global_load_lds is a device-only builtin: the host pass of hipcc must not see it)
   typedef double vec2 __attribute__((ext_vector_type(2)));
-  typedef __attribute__((address_space(3))) void lds_void;
+  vec2 stageA[3], stageB[3];
 #define MUGIQ_MT_BODY(n_) static_cast<const Cplx<double> *>(as_constant(a.L)[n_])
 #define MUGIQ_MT_SIGMA(n_) as_constant(a.inv_sigma)[n_]
-  // this wave's share of eigenvector n_ -> tile buffer buf_: 6 transfers of 64 x 16 bytes
-#define MUGIQ_MT_GLDS(bodyExpr_, n_, buf_)                                                                             \
-  {                                                                                                                    \
-    const Cplx<double> *body_ = bodyExpr_;                                                                             \
-    const Cplx<double> *gh_ = ghostBase + (int64_t)(n_)*a.ghost_vec_stride;                                            \
-    Cplx<double> *dst_ = (buf_) + (size_t)wave * kMT_PerWave * kMT_Chunk;                                              \
-    _Pragma("unroll") for (int i = 0; i < kMT_PerWave; i++) {                                                          \
-      const Cplx<double> *ptr_ = (((sghost >> i) & 1u) ? gh_ : body_) + soff[i];                                       \
-      __builtin_amdgcn_global_load_lds(as_global(reinterpret_cast<const vec2 *>(ptr_)), (lds_void *)(dst_ + (size_t)i * kMT_Chunk), 16, 0, 0); \
+  // this thread's three colours of eigenvector n_ (unconditional for the staging waves: a known number of loads in flight)
+#define MUGIQ_MT_FETCH(bodyExpr_, n_, stage)                                                                           \
+  if (stages) {                                                                                                        \
+    const Cplx<double> *src_ = (fromGhost ? ghostBase + (int64_t)(n_)*a.ghost_vec_stride : (bodyExpr_)) + soff;        \
+    _Pragma("unroll") for (int c = 0; c < 3; c++) stage[c] = *as_global(reinterpret_cast<const vec2 *>(src_ + (int64_t)c * cstride)); \
+  }
+  // v' = g v into tile buffer buf_
+#define MUGIQ_MT_COMMIT(stage, buf_)                                                                                   \
+  if (stages) {                                                                                                        \
+    Cplx<double> *dst_ = (buf_) + wIdx;                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 3; i++) {                                                                    \
+      Cplx<double> r{0.0, 0.0};                                                                                        \
+      _Pragma("unroll") for (int j = 0; j < 3; j++) cmadd(r, g[i * 3 + j], Cplx<double>{stage[j].x, stage[j].y});      \
+      dst_[i * kMT_Chunk] = r;                                                                                         \
     }                                                                                                                  \
   }
 #define MUGIQ_MT_BARRIER()                              \
   {                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    if (MUGIQ_MT_EXPERIMENT < 2) __builtin_amdgcn_s_barrier(); \
+    if (MUGIQ_MT_EXPERIMENT != 2 && MUGIQ_MT_EXPERIMENT != 3) __builtin_amdgcn_s_barrier(); \
     asm volatile("" ::: "memory");                      \
   }
-  // the arithmetic of one eigenvector (scaled by s_) on the tile buffer tile_
+  // the products of one eigenvector (scaled by s_) on the tile buffer tile_
 #define MUGIQ_MT_COMPUTE(tile_, s_)                                                                                    \
   {                                                                                                                    \
     const Cplx<double> *tile = tile_;                                                                                  \
-    const double sc = s_;                                                                                              \
-    Cplx<double> vv[kMT_Groups], pp_[kMT_Groups][NS];                                                                \
-    _Pragma("unroll") for (int g = 0; g < kMT_Groups; g++) {                                                           \
-      if (MUGIQ_MT_EXPERIMENT >= 3) {                                                                                  \
-        vv[g] = Cplx<double>{WR[g][0] + sc, WI[g][0] - sc};                                                            \
-        _Pragma("unroll") for (int s = 0; s < NS; s++) pp_[g][s] = Cplx<double>{WI[g][s] * sc, WR[g][s] + sc};         \
-        continue;                                                                                                      \
-      }                                                                                                                \
-      vv[g] = tile[vIdx + 4 * g];                                                                                      \
-      _Pragma("unroll") for (int s = 0; s < NS; s++) pp_[g][s] = tile[pIdx[s] + 4 * g];                                \
-    }                                                                                                                  \
-    if (HOIST) __builtin_amdgcn_sched_barrier(0); /* all operand reads of the step in flight before the first product */ \
-    _Pragma("unroll") for (int g = 0; g < kMT_Groups; g++) {                                                           \
-      const Cplx<double> v = vv[g];                                                                                    \
+    const double sc = (s_)*colourMask;                                                                                 \
+    _Pragma("unroll") for (int gi = 0; gi < kMT_Groups; gi++) {                                                        \
+      const Cplx<double> v = tile[vIdx[gi]];                                                                           \
       const double VR = sc * v.re, VI = sc * v.im, nVI = -VI;                                                          \
       _Pragma("unroll") for (int s = 0; s < NS; s++) {                                                                 \
-        const Cplx<double> p = pp_[g][s];                                                                              \
-        double tR = MUGIQ_MFMA(WR[g][s], p.re, 0.0);                                                                   \
-        double tI = MUGIQ_MFMA(WI[g][s], p.re, 0.0);                                                                   \
-        tR = MUGIQ_MFMA(nWI[g][s], p.im, tR);                                                                          \
-        tI = MUGIQ_MFMA(WR[g][s], p.im, tI);                                                                           \
-        aR[g][s] = MUGIQ_MFMA(VR, tR, aR[g][s]);                                                                       \
-        aI[g][s] = MUGIQ_MFMA(VR, tI, aI[g][s]);                                                                       \
-        aR[g][s] = MUGIQ_MFMA(VI, tI, aR[g][s]);                                                                       \
-        aI[g][s] = MUGIQ_MFMA(nVI, tR, aI[g][s]);                                                                      \
+        const Cplx<double> p = tile[pIdx[gi][s]];                                                                      \
+        aR[gi][s] = MUGIQ_MFMA(VR, p.re, aR[gi][s]);                                                                   \
+        aI[gi][s] = MUGIQ_MFMA(VR, p.im, aI[gi][s]);                                                                   \
+        aR[gi][s] = MUGIQ_MFMA(VI, p.im, aR[gi][s]);                                                                   \
+        aI[gi][s] = MUGIQ_MFMA(nVI, p.re, aI[gi][s]);                                                                  \
       }                                                                                                                \
     }                                                                                                                  \
   }
-  // One step: eigenvector n_ lands in buffer cur_ (own share: counted vmcnt wait; everybody's: the barrier, which also says
-  // that nobody reads buffer nxt2_ = the one consumed in the previous step any more); eigenvector n_+2 is sent there, n_+1
-  // stays in flight, n_ is consumed.
-#define MUGIQ_MT_STEP(n_, cur_, nxt2_, STEADY)                                                                         \
+  // One step: v'(n_) is in buffer n_ & 1; `stage` holds the raw eigenvector n_ + 1 (fetched two steps ago).  Rotate and commit
+  // it into the other buffer (everybody finished reading that one before the barrier that ended the previous step), refill
+  // `stage` with n_ + 3, consume n_, one barrier.
+#define MUGIQ_MT_STEP(n_, stage, GUARD)                                                                                \
   {                                                                                                                    \
     const double sNow = sigPre;                                                                                        \
     const Cplx<double> *bodyNow = bodyPre;                                                                             \
-    if (MUGIQ_MT_EXPERIMENT == 0 && (STEADY || (n_) + 1 < a.nVec)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kMT_PerWave) : "memory"); \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
-    MUGIQ_MT_BARRIER()                                                                                                 \
-    if (MUGIQ_MT_EXPERIMENT == 0 && (STEADY || (n_) + 2 < a.nVec)) MUGIQ_MT_GLDS(bodyNow, (n_) + 2, nxt2_)             \
-    MUGIQ_MT_COMPUTE(cur_, sNow)                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                                 \
     {                                                                                                                  \
-      const int nb_ = (n_) + 3 < a.nVec ? (n_) + 3 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1;      \
+      const int nb_ = (n_) + 4 < a.nVec ? (n_) + 4 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1;      \
       bodyPre = MUGIQ_MT_BODY(nb_);                                                                                    \
       sigPre = MUGIQ_MT_SIGMA(ns_);                                                                                    \
     }                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    if (MUGIQ_MT_EXPERIMENT != 3 && (GUARD == 0 || (n_) + 1 < a.nVec)) MUGIQ_MT_COMMIT(stage, tileBase + (size_t)(((n_) + 1) & 1) * kMT_BufElems) \
+    if ((MUGIQ_MT_EXPERIMENT == 0 || MUGIQ_MT_EXPERIMENT == 4) && (GUARD == 0 || (n_) + 3 < a.nVec)) MUGIQ_MT_FETCH(bodyNow, (n_) + 3, stage) \
+    if (MUGIQ_MT_EXPERIMENT != 4) MUGIQ_MT_COMPUTE(tileBase + (size_t)((n_) & 1) * kMT_BufElems, sNow)                 \
+    MUGIQ_MT_BARRIER()                                                                                                 \
   }
-  Cplx<double> *const buf0 = tileBase, *const buf1 = tileBase + kMT_BufElems, *const buf2 = tileBase + 2 * kMT_BufElems;
-  const int last = a.nVec - 1;
-  MUGIQ_MT_GLDS(MUGIQ_MT_BODY(0), 0, buf0)
-  MUGIQ_MT_GLDS(MUGIQ_MT_BODY((1 < last ? 1 : last)), (1 < last ? 1 : last), buf1)  // (unconditional: known count in flight)
-  const Cplx<double> *bodyPre = MUGIQ_MT_BODY((2 < last ? 2 : last));
+  // prologue: eigenvector 0 -> buffer 0; eigenvectors 1 and 2 in flight (clamped, unconditional)
+  {
+    const int last = a.nVec - 1;
+    MUGIQ_MT_FETCH(MUGIQ_MT_BODY(0), 0, stageB)
+    MUGIQ_MT_COMMIT(stageB, tileBase)
+    MUGIQ_MT_FETCH(MUGIQ_MT_BODY((1 < last ? 1 : last)), (1 < last ? 1 : last), stageA)
+    MUGIQ_MT_FETCH(MUGIQ_MT_BODY((2 < last ? 2 : last)), (2 < last ? 2 : last), stageB)
+  }
+  const Cplx<double> *bodyPre = MUGIQ_MT_BODY(a.nVec > 3 ? 3 : a.nVec - 1);
   double sigPre = MUGIQ_MT_SIGMA(0);
+  MUGIQ_MT_BARRIER()
   int n = 0;
-  for (; n + 4 < a.nVec; n += 3) {
-    MUGIQ_MT_STEP(n, buf0, buf2, 1)
-    MUGIQ_MT_STEP(n + 1, buf1, buf0, 1)
-    MUGIQ_MT_STEP(n + 2, buf2, buf1, 1)
+  for (; n + 4 < a.nVec; n += 2) {
+    MUGIQ_MT_STEP(n, stageA, 0)
+    MUGIQ_MT_STEP(n + 1, stageB, 0)
   }
-  for (; n < a.nVec; n += 3) {  // n % 3 == 0 here
-    MUGIQ_MT_STEP(n, buf0, buf2, 0)
-    if (n + 1 < a.nVec) MUGIQ_MT_STEP(n + 1, buf1, buf0, 0)
-    if (n + 2 < a.nVec) MUGIQ_MT_STEP(n + 2, buf2, buf1, 0)
+  for (; n < a.nVec; n += 2) {
+    MUGIQ_MT_STEP(n, stageA, 1)
+    if (n + 1 < a.nVec) MUGIQ_MT_STEP(n + 1, stageB, 1)
   }
 #undef MUGIQ_MT_STEP
 #undef MUGIQ_MT_COMPUTE
-#undef MUGIQ_MT_GLDS
+#undef MUGIQ_MT_COMMIT
+#undef MUGIQ_MT_FETCH
 #undef MUGIQ_MT_BODY
 #undef MUGIQ_MT_SIGMA
 
-  // ---- epilogue: lane 16 be + 4 b + al holds element (be, al) of the spin matrix of site b.  Through LDS (the tile buffers
-  // are free now) as [slot][be * 4 + al][site = position * 32 + line], then one thread per (slot, site, half of the gamma
-  // channels) as in csrc/fused_tile.hip: consecutive lanes <-> consecutive lines, so the stores stay coalesced per channel.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  MUGIQ_MT_BARRIER()
+  // ---- epilogue: lane 16 be + 4 b + al holds element (be, al) of the spin matrix of site b.  Slot by slot through LDS (the
+  // tile buffers are free now) as [be * 4 + al][site = position * LN + line], then one thread per (site, half of the gamma
+  // channels): consecutive lanes <-> consecutive lines, so the stores stay coalesced per channel.
   Cplx<double> *scratch = tileBase;
 #pragma unroll
-  for (int g = 0; g < kMT_Groups; g++)
+  for (int s = 0; s < NS; s++) {
 #pragma unroll
-    for (int s = 0; s < NS; s++)
-      scratch[(s * 16 + hi * 4 + lo) * 128 + wpos * kMT_Cols + lineBase + 4 * g] = Cplx<double>{aR[g][s], aI[g][s]};
-  MUGIQ_MT_BARRIER()
-  for (int item = threadIdx.x; item < 256 * NS; item += 64 * kMT_Waves) {
-    const int site = item & 127, half = (item >> 7) & 1, s = item >> 8;
-    const int pos = site >> 5;
-    int p0, base, faceIdx;
-    bool ok;
-    line_info(site & 31, p0, base, faceIdx, ok);
-    if (!ok) continue;
-    const int jmine = j0 + pos;
-    const int pmine = p0 ^ (jmine & 1), xmine = base + jmine * a.strideMu;
-    Cplx<double> full[16];
+    for (int gi = 0; gi < kMT_Groups; gi++) {
+      const int gid = wave * kMT_Groups + gi;
+      scratch[(hi * 4 + lo) * kSites + (gid / kGP) * kMT_Cols + 4 * (gid % kGP) + b] = Cplx<double>{aR[gi][s], aI[gi][s]};
+    }
+    MUGIQ_MT_BARRIER()
+    for (int item = t; item < 2 * kSites; item += 64 * kMT_Waves) {
+      const int half = item / kSites, site = item - half * kSites;
+      const int pos = site / kMT_Cols;
+      const int cid = cc * kMT_Cols + (site % kMT_Cols);
+      if (cid >= a.numCols) continue;
+      int p0, base;
+      mt_line(cid, a.H, a.strideMu, J, p0, base);
+      const int jmine = j0 + pos;
+      const int pmine = p0 ^ (jmine & 1), xmine = base + jmine * a.strideMu;
+      Cplx<double> full[16];
 #pragma unroll
-    for (int e = 0; e < 16; e++) full[e] = scratch[(s * 16 + e) * 128 + site];
-    const int siteIdx = xmine + pmine * a.volumeCB;
-    if (half == 0) trace_and_store_range<double, 0, 8>(a.out[s], full, 2 * a.volumeCB, siteIdx, a.overwrite != 0);
-    else trace_and_store_range<double, 8, 16>(a.out[s], full, 2 * a.volumeCB, siteIdx, a.overwrite != 0);
+      for (int e = 0; e < 16; e++) full[e] = scratch[e * kSites + site];
+      const int siteIdx = xmine + pmine * a.volumeCB;
+      if (half == 0) trace_and_store_range<double, 0, 8>(a.out[s], full, 2 * a.volumeCB, siteIdx, a.overwrite != 0);
+      else trace_and_store_range<double, 8, 16>(a.out[s], full, 2 * a.volumeCB, siteIdx, a.overwrite != 0);
+    }
+    if (s + 1 < NS) MUGIQ_MT_BARRIER()
   }
 #undef MUGIQ_MT_BARRIER
-#endif
 }
 #undef MUGIQ_MFMA
 
-// Can the matrix-pipe tile take this entry?  fp64 FLOAT2 storage and loops, mu = y, z, t, at most 8 staged positions.
-// MUGIQ_HIP_TILE_MFMA = 0 switches it off (the vector tiles of csrc/fused_tile.hip / fused_tile16.hip take over).
-bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int partitioned) {
+// The tile geometry for an entry: the first TJ of {8, 12, 4} that divides the extent and keeps TJ + Kmax within the staged
+// positions of its line count (MUGIQ_HIP_MFMA_TJ = 4 | 8 | 12 fixes it); 0 = none.
+static int mfma_tile_tj(int extent, int kmax) {
+  int want = 0;
+  if (const char *e = getenv("MUGIQ_HIP_MFMA_TJ")) want = atoi(e);
+  for (int tj : {8, 12, 4}) {  // (measured: 8 positions x 16 lines beats 12 x 16 -- three groups per wave, spills with four slots -- and 4 x 32)
+    if (want && tj != want) continue;
+    if (extent % tj != 0 || tj + kmax > (tj == 4 ? 8 : 16)) continue;
+    return tj;
+  }
+  return 0;
+}
+
+// Can the axial-gauge tile take this entry?  fp64 FLOAT2 storage and loops, mu = y, z, t, lengths 1 .. Kmax (the gauge is
+// built from W_1 .. W_Kmax).  MUGIQ_HIP_TILE_MFMA = 0 switches it off (the vector tiles of csrc/fused_tile.hip /
+// fused_tile16.hip take over).
+bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, const int *kvals, int nK, int partitioned) {
   if (const char *e = getenv("MUGIQ_HIP_TILE_MFMA"))
     if (atoi(e) == 0) return false;
   if (const char *e = getenv("MUGIQ_HIP_FUSED_TILE"))
@@ -313,30 +391,30 @@ bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, int kmax, int 
     if (atoi(e) == 0) return false;  // register-staged vector tile asked for
   if (ev.precision != 8 || ev.field_order != 2 || dir < 1) return false;
   if (2 * (int64_t)ev.parity_offset >= (1LL << 31)) return false;  // the kernel keeps 32-bit element offsets
-  if (ev.X[dir] % kMT_TJ != 0 || kmax > ev.X[dir]) return false;
-  return kMT_TJ + kmax <= 2 * kMT_Pairs;
+  for (int i = 0; i < nK; i++)
+    if (kvals[i] != i + 1) return false;  // W_1 .. W_Kmax, all of them, in order
+  const int kmax = nK;
+  if (kmax > kMT_MaxSlots - 1 || kmax > ev.X[dir]) return false;
+  return mfma_tile_tj(ev.X[dir], kmax) != 0;
 }
 
-static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, hipStream_t stream) {
-  const size_t shmem = (size_t)3 * kMT_BufElems * sizeof(Cplx<double>);
-  const unsigned nblocks = (unsigned)(((a.numCols + kMT_Cols - 1) / kMT_Cols) * a.jtCount);
+static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, hipStream_t stream) {
+  const int ln = tj == 4 ? 32 : 16;
+  const size_t shmem = std::max((size_t)2 * kMT_BufElems * sizeof(Cplx<double>), (size_t)16 * tj * ln * sizeof(Cplx<double>));
+  const unsigned nblocks = (unsigned)(((a.numCols + ln - 1) / ln) * a.jtCount);
   a.blockOrder = 2;
   if (const char *e = getenv("MUGIQ_HIP_TILE_ORDER")) a.blockOrder = atoi(e) & 2;
   if (nblocks % 8 != 0) a.blockOrder = 0;
-  int groups = 4, hoist = 0;
-  if (const char *e = getenv("MUGIQ_HIP_MFMA_GROUPS")) groups = atoi(e) == 2 ? 2 : 4;
-  if (const char *e = getenv("MUGIQ_HIP_MFMA_HOIST")) hoist = atoi(e) != 0;
-  const dim3 grid(nblocks), block(64 * 32 / groups);
-#define MUGIQ_MT_LAUNCH_(D, S, N, GG, HH)                                                                                     \
-  {                                                                                                                    \
-    auto kern = mfma_tile_displaced_contract_kernel<D, S, N, GG, HH>;                                                  \
-    MUGIQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-    hipLaunchKernelGGL(kern, grid, block, shmem, stream, a);                                                           \
-  }
+  const dim3 grid(nblocks), block(64 * kMT_Waves);
 #define MUGIQ_MT_LAUNCH(D, S, N)                                                                                       \
   {                                                                                                                    \
-    if (groups == 2 && hoist) MUGIQ_MT_LAUNCH_(D, S, N, 2, true) else if (groups == 2) MUGIQ_MT_LAUNCH_(D, S, N, 2, false)   \
-    else if (hoist) MUGIQ_MT_LAUNCH_(D, S, N, 4, true) else MUGIQ_MT_LAUNCH_(D, S, N, 4, false)                           \
+    if (tj == 12) MUGIQ_MT_LAUNCH_(D, S, N, 12, 16) else if (tj == 8) MUGIQ_MT_LAUNCH_(D, S, N, 8, 16) else MUGIQ_MT_LAUNCH_(D, S, N, 4, 32) \
+  }
+#define MUGIQ_MT_LAUNCH_(D, S, N, T, LL)                                                                               \
+  {                                                                                                                    \
+    auto kern = mfma_tile_displaced_contract_kernel<D, S, N, T, LL>;                                                   \
+    MUGIQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+    hipLaunchKernelGGL(kern, grid, block, shmem, stream, a);                                                           \
   }
 #define MUGIQ_MT_CASE(D, S)                                                                                            \
   case (D)*2 + (S):                                                                                                    \
@@ -354,8 +432,8 @@ static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, hipStream_t 
   return MUGIQ_HIP_SUCCESS;
 }
 
-// ultra_d != NULL: also produce the ultra-local loop (k = 0, W = 1) into ultra_d as one more slot of the first launch; *carried
-// says whether that happened (only a launch over the whole lattice may: see csrc/fused_tile.hip)
+// ultra_d != NULL: also produce the ultra-local loop (k = 0) into ultra_d as one more slot; *carried says whether that
+// happened (only a launch over the whole lattice may: see csrc/fused_tile.hip)
 int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d, const int *kvals,
                     int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, int region, hipStream_t stream,
                     void *ultra_d, int *carried) {
@@ -392,47 +470,62 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
   a.strideMu = (int)strideMu;
   a.H = (int)(ev[0].volumeCB / (ev[0].X[dir] * strideMu));
   a.numCols = 2 * ev[0].volumeCB / ev[0].X[dir];
-  const int nJT = ev[0].X[dir] / kMT_TJ;
+  const int tj = mfma_tile_tj(ev[0].X[dir], nK);
+  MUGIQ_REQUIRE(tj != 0, "mfma tile: no tile geometry for extent %d, lengths 1..%d (internal)", ev[0].X[dir], nK);
+  const int nJT = ev[0].X[dir] / tj;
   a.overwrite = (region & MUGIQ_HIP_REGION_OVERWRITE) ? 1 : 0;
   region &= 0xff;
   if (region != MUGIQ_HIP_REGION_ALL) ultra_d = nullptr;
-  const int perLaunch = kMT_MaxSlots - 1;  // displaced slots per launch
-  for (int k0 = 0; k0 < nK; k0 += perLaunch) {
-    int ns = std::min(nK - k0, perLaunch);
-    a.kmax = 0;
-    for (int s = 0; s < kMT_MaxSlots; s++) {
-      const int i = k0 + (s < ns ? s : 0);
-      a.E[s] = static_cast<const double *>(E_d[i]);
-      a.k[s] = kvals[i];
-      a.out[s] = static_cast<Cplx<double> *>(loop_d) + (int64_t)i * slot_stride;
-      if (s < ns && kvals[i] > a.kmax) a.kmax = kvals[i];
+  a.kmax = nK;  // (mfma_tile_applicable: the lengths are 1 .. nK)
+  // the axial gauge of this (direction, sign), rebuilt per call into the stream's workspace (one pass over W_1)
+  {
+    const size_t gBytes = (size_t)9 * (ev[0].X[dir] + a.kmax) * a.numCols * sizeof(Cplx<double>);
+    void *gbuf = nullptr;
+    if ((st = stream_workspace(&gbuf, gBytes, stream))) return st;
+    AxialArgs g;
+    g.G = static_cast<Cplx<double> *>(gbuf);
+    for (int l = 0; l < 4; l++) g.E[l] = static_cast<const Cplx<double> *>(E_d[l < nK ? l : 0]);
+    g.kmax = a.kmax;
+    g.sign = sign;
+    g.J = ev[0].X[dir];
+    g.strideMu = a.strideMu;
+    g.H = a.H;
+    g.numCols = a.numCols;
+    g.volumeCB = a.volumeCB;
+    hipLaunchKernelGGL(axial_gauge_kernel, dim3((a.numCols + 63) / 64), dim3(64), 0, stream, g);
+    MUGIQ_CHECK_HIP(hipGetLastError());
+    a.G = g.G;
+  }
+  int ns = nK;
+  for (int s = 0; s < kMT_MaxSlots; s++) {
+    const int i = s < ns ? s : 0;
+    a.k[s] = kvals[i];
+    a.out[s] = static_cast<Cplx<double> *>(loop_d) + (int64_t)i * slot_stride;
+  }
+  bool withUltra = false;
+  if (ultra_d) {
+    a.k[ns] = 0;
+    a.out[ns] = static_cast<Cplx<double> *>(ultra_d);
+    ns++;
+    withUltra = true;
+  }
+  // region 0: everything | 1: tiles whose shifted reads stay inside the local lattice | 2: tiles that read ghost layers
+  a.jtBegin = 0;
+  a.jtCount = nJT;
+  if (region != MUGIQ_HIP_REGION_ALL) {
+    const int nb = partitioned ? std::min(nJT, (a.kmax + tj - 1) / tj) : 0;  // boundary tiles
+    if (region == MUGIQ_HIP_REGION_INTERIOR) {
+      a.jtBegin = sign == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : nb;
+      a.jtCount = nJT - nb;
+    } else {
+      a.jtBegin = sign == MUGIQ_HIP_DISP_SIGN_PLUS ? nJT - nb : 0;
+      a.jtCount = nb;
     }
-    bool withUltra = false;
-    if (ultra_d && k0 == 0) {
-      a.E[ns] = nullptr;
-      a.k[ns] = 0;
-      a.out[ns] = static_cast<Cplx<double> *>(ultra_d);
-      ns++;
-      withUltra = true;
-    }
-    // region 0: everything | 1: tiles whose shifted reads stay inside the local lattice | 2: tiles that read ghost layers
-    a.jtBegin = 0;
-    a.jtCount = nJT;
-    if (region != MUGIQ_HIP_REGION_ALL) {
-      const int nb = partitioned ? std::min(nJT, (a.kmax + kMT_TJ - 1) / kMT_TJ) : 0;  // boundary tiles
-      if (region == MUGIQ_HIP_REGION_INTERIOR) {
-        a.jtBegin = sign == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : nb;
-        a.jtCount = nJT - nb;
-      } else {
-        a.jtBegin = sign == MUGIQ_HIP_DISP_SIGN_PLUS ? nJT - nb : 0;
-        a.jtCount = nb;
-      }
-    }
-    if (a.jtCount > 0) {
-      st = launch_mfma_tile(a, dir, sign, ns, stream);
-      if (st) return st;
-      if (withUltra && carried) *carried = 1;
-    }
+  }
+  if (a.jtCount > 0) {
+    st = launch_mfma_tile(a, dir, sign, ns, tj, stream);
+    if (st) return st;
+    if (withUltra && carried) *carried = 1;
   }
   return MUGIQ_HIP_SUCCESS;
 }
