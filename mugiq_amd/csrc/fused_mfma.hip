@@ -70,6 +70,8 @@ struct MTileArgs {
   int jtCount;
   int blockOrder; // bit 1: XCD-contiguous workgroup order
   int overwrite;  // store instead of accumulate (MUGIQ_HIP_REGION_OVERWRITE)
+  int rowsPerTile;  // mu = x: whole x rows per workgroup (R), and the chunk stride of their LDS image
+  int rowChunk;
 };
 
 // line `cid` of direction mu: parity and checkerboard index of its j = 0 site
@@ -88,6 +90,7 @@ struct AxialArgs {
   Cplx<double> *G;
   const Cplx<double> *E[4];  // E_1 .. E_kmax
   int kmax, sign, J, strideMu, H, numCols, volumeCB;
+  int rowMode, X1, X2;  // mu = x: line = x row `cid`, site j <-> (parity p0 ^ (j & 1), entry cid J/2 + j/2); G is [9][row][position]
 };
 __device__ inline void mt_load_w(Cplx<double> w[9], const Cplx<double> *E, int par, int x_cb, int volumeCB) {
   const Cplx<double> *e = E + (int64_t)par * 12 * volumeCB + x_cb;
@@ -115,24 +118,31 @@ __global__ __launch_bounds__(64) void axial_gauge_kernel(AxialArgs a) {
   const int cid = blockIdx.x * 64 + threadIdx.x;
   if (cid >= a.numCols) return;
   int p0, base;
-  mt_line(cid, a.H, a.strideMu, a.J, p0, base);
+  if (a.rowMode) {
+    const int zt = cid / a.X1;
+    p0 = (cid % a.X1 + zt % a.X2 + zt / a.X2) & 1;
+    base = cid * (a.J >> 1);
+  } else {
+    mt_line(cid, a.H, a.strideMu, a.J, p0, base);
+  }
   const int Jext = a.J + a.kmax;
   auto store = [&](int jext, const Cplx<double> g[9]) {
 #pragma unroll
-    for (int c = 0; c < 9; c++) a.G[((int64_t)c * Jext + jext) * a.numCols + cid] = g[c];
+    for (int c = 0; c < 9; c++) a.G[a.rowMode ? ((int64_t)c * a.numCols + cid) * Jext + jext : ((int64_t)c * Jext + jext) * a.numCols + cid] = g[c];
   };
+  auto site_xcb = [&](int j) { return a.rowMode ? base + (j >> 1) : base + j * a.strideMu; };
   Cplx<double> g[9], w[9], t[9];
 #pragma unroll
   for (int c = 0; c < 9; c++) g[c] = Cplx<double>{c % 4 == 0 ? 1.0 : 0.0, 0.0};
   const int off = a.sign == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : a.kmax;
   if (a.sign == MUGIQ_HIP_DISP_SIGN_MINUS) {  // g(-l) = W^-_l(x_0)
     for (int l = 1; l <= a.kmax; l++) {
-      mt_load_w(w, a.E[l - 1], p0, base, a.volumeCB);
+      mt_load_w(w, a.E[l - 1], p0, site_xcb(0), a.volumeCB);
       store(a.kmax - l, w);
     }
   }
   for (int j = 0; j < a.J; j++) {
-    const int par = p0 ^ (j & 1), x_cb = base + j * a.strideMu;
+    const int par = p0 ^ (j & 1), x_cb = site_xcb(j);
     if (a.sign == MUGIQ_HIP_DISP_SIGN_MINUS && j > 0) {  // g(j) = g(j - 1) W^-_1(x_j)^dag      (W^-_1(x) = U(x - mu)^dag)
       mt_load_w(w, a.E[0], par, x_cb, a.volumeCB);
       mt_mul3<true>(t, g, w);
@@ -162,13 +172,18 @@ __global__ __launch_bounds__(64) void axial_gauge_kernel(AxialArgs a) {
 #define MUGIQ_MT_EXPERIMENT 0  // probe builds only (tools/probes/build_exp.sh): 1 no global loads in the steps, 2 + no barrier, 3 + no rotation / commit, 4 staging only (no products)
 #endif
 
+// mu = x (DIR == 0, "row tile"): the lines run along the coalescing direction, so a workgroup owns R whole x rows (both
+// parities; R X0 = 128 | 192 sites, TJ = 0 and LN = 16 * groups per wave in the template) and there is no halo at all: the
+// positions past the end of the row (sign +) or before its start (sign -) are the row's own first / last sites, staged a
+// second time with the continued gauge g(J + l) | g(-l).  LDS image: chunk (parity, component) = [row][X0/2 + 2] complex.
 template <int DIR, int SIGN, int NS, int TJ, int LN>
 __global__ __launch_bounds__(64 * kMT_Waves) void mfma_tile_displaced_contract_kernel(MTileArgs a) {
+  constexpr bool kRow = DIR == 0;
   constexpr int kMT_TJ = TJ, kMT_Cols = LN;
-  constexpr int kPPC = 64 / LN;                              // positions per chunk (2 | 4)
-  constexpr int kMT_Groups = TJ * LN / 4 / kMT_Waves;        // 4-site groups per wave
-  constexpr int kGP = LN / 4;                                // groups per position
-  constexpr int kSites = TJ * LN;
+  constexpr int kPPC = kRow ? 1 : 64 / LN;                          // positions per chunk (2 | 4)
+  constexpr int kMT_Groups = kRow ? LN / 16 : TJ * LN / 4 / kMT_Waves;  // 4-site groups per wave
+  constexpr int kGP = LN / 4;                                       // groups per position
+  constexpr int kSites = kMT_Groups * 64;
   extern __shared__ __align__(16) unsigned char smem[];
   Cplx<double> *tileBase = reinterpret_cast<Cplx<double> *>(smem);  // 2 x [pair][12][68]
   const int t = threadIdx.x, lane = t & 63;
@@ -187,7 +202,7 @@ __global__ __launch_bounds__(64 * kMT_Waves) void mfma_tile_displaced_contract_k
 
   // ---- staging role: thread <-> (position t / (4 LN), spin, line t % LN); three colours each
   const int spp = LN == 32 ? wave >> 1 : wave, sspin = (t / LN) & 3, sline = t & (LN - 1);
-  const bool stages = spp < NP;  // (wave-uniform: the waves of the unused positions only compute)
+  const bool stages = kRow || spp < NP;  // (wave-uniform: the waves of the unused positions only compute)
 
   int soff = 0, cstride = a.stride;
   bool fromGhost = false;
@@ -195,7 +210,33 @@ __global__ __launch_bounds__(64 * kMT_Waves) void mfma_tile_displaced_contract_k
 #pragma unroll
   for (int c = 0; c < 9; c++) g[c] = Cplx<double>{0.0, 0.0};
   int wIdx = 0;
-  if (stages) {
+  const int compStride = kRow ? a.rowChunk : kMT_Chunk;  // distance of two components in the LDS image
+  bool commits = stages;
+  // row tile: rows of X0/2 entries per parity, + 2 slots for the continued positions (element m <-> position 2 (m - off) + delta)
+  const int EPR = a.X[0] >> 1, EPRX = EPR + 2, rOff = SIGN == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : 2;
+  auto row_delta = [&](int rowG, int parity) {  // x of the first entry of (row, parity): (parity + y + z + t) & 1
+    const int y = rowG % a.X[1], zt = rowG / a.X[1];
+    return (parity + y + zt % a.X[2] + zt / a.X[2]) & 1;
+  };
+  if constexpr (kRow) {
+    const int R = a.rowsPerTile, nItems = R * 8 * EPRX;
+    const int q = t < nItems ? t : nItems - 1;
+    const int mm = q % EPRX, rest = q / EPRX;
+    const int spin = rest & 3, pr = rest >> 2, parity = pr / R, row = pr - parity * R;
+    const int rowG = blk * R + row;
+    const int j = 2 * (mm - rOff) + row_delta(rowG, parity);  // position along x; beyond [0, J): a continued one
+    const bool valid = t < nItems && (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS ? (j < J + a.kmax) : (j >= -a.kmax && j < J));
+    const int jv = valid ? j : row_delta(rowG, parity);  // (invalid items fetch the first entry of their row and commit nothing)
+    const int js = jv < 0 ? jv + J : (jv >= J ? jv - J : jv);  // J is even: the wrapped site has the same parity
+    const int jext = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? jv : jv + a.kmax;
+    const int Jext = J + a.kmax;
+    const int par = parity;
+#pragma unroll
+    for (int c = 0; c < 9; c++) g[c] = a.G[((int64_t)c * a.numCols + rowG) * Jext + jext];
+    soff = (int)((int64_t)par * a.parity_offset + (int64_t)(3 * spin) * a.stride + (int64_t)rowG * EPR + (js >> 1));
+    wIdx = (parity * 12 + 3 * spin) * a.rowChunk + row * EPRX + mm;
+    commits = valid;
+  } else if (stages) {
     int cid = cc * kMT_Cols + sline;
     if (cid >= a.numCols) cid = a.numCols - 1;  // surplus lines shadow the last one (valid addresses, result dropped)
     int p0, base;
@@ -229,6 +270,18 @@ __global__ __launch_bounds__(64 * kMT_Waves) void mfma_tile_displaced_contract_k
   int vIdx[kMT_Groups], pIdx[kMT_Groups][NS];
 #pragma unroll
   for (int gi = 0; gi < kMT_Groups; gi++) {
+    if constexpr (kRow) {  // group = 4 consecutive entries of one (parity, row)
+      const int R = a.rowsPerTile, gid = wave * kMT_Groups + gi, gpr = EPR / 4;
+      const int m0 = 4 * (gid % gpr), pr = gid / gpr, parity = pr / R, row = pr - parity * R;
+      const int j = 2 * (m0 + b) + row_delta(blk * R + row, parity);
+      vIdx[gi] = (parity * 12 + compRd) * a.rowChunk + row * EPRX + m0 + b + rOff;
+#pragma unroll
+      for (int s = 0; s < NS; s++) {
+        const int js = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? j + a.k[s] : j - a.k[s];
+        pIdx[gi][s] = ((parity ^ (a.k[s] & 1)) * 12 + compRd) * a.rowChunk + row * EPRX + ((js + 2 * rOff) >> 1);
+      }
+      continue;
+    }
     const int gid = wave * kMT_Groups + gi, gpos = gid / kGP, gline = 4 * (gid % kGP) + b;
     vIdx[gi] = elemIdx((SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? gpos : a.kmax + gpos, gline);
 #pragma unroll
@@ -254,12 +307,12 @@ __global__ __launch_bounds__(64 * kMT_Waves) void mfma_tile_displaced_contract_k
   }
   // v' = g v into tile buffer buf_
 #define MUGIQ_MT_COMMIT(stage, buf_)                                                                                   \
-  if (stages) {                                                                                                        \
+  if (commits) {                                                                                                       \
     Cplx<double> *dst_ = (buf_) + wIdx;                                                                                \
     _Pragma("unroll") for (int i = 0; i < 3; i++) {                                                                    \
       Cplx<double> r{0.0, 0.0};                                                                                        \
       _Pragma("unroll") for (int j = 0; j < 3; j++) cmadd(r, g[i * 3 + j], Cplx<double>{stage[j].x, stage[j].y});      \
-      dst_[i * kMT_Chunk] = r;                                                                                         \
+      dst_[i * compStride] = r;                                                                                        \
     }                                                                                                                  \
   }
 #define MUGIQ_MT_BARRIER()                              \
@@ -339,18 +392,28 @@ __global__ __launch_bounds__(64 * kMT_Waves) void mfma_tile_displaced_contract_k
 #pragma unroll
     for (int gi = 0; gi < kMT_Groups; gi++) {
       const int gid = wave * kMT_Groups + gi;
-      scratch[(hi * 4 + lo) * kSites + (gid / kGP) * kMT_Cols + 4 * (gid % kGP) + b] = Cplx<double>{aR[gi][s], aI[gi][s]};
+      // (row tile: site = (parity R + row) X0/2 + entry = 4 gid + b)
+      const int site = kRow ? 4 * gid + b : (gid / kGP) * kMT_Cols + 4 * (gid % kGP) + b;
+      scratch[(hi * 4 + lo) * kSites + site] = Cplx<double>{aR[gi][s], aI[gi][s]};
     }
     MUGIQ_MT_BARRIER()
     for (int item = t; item < 2 * kSites; item += 64 * kMT_Waves) {
       const int half = item / kSites, site = item - half * kSites;
-      const int pos = site / kMT_Cols;
-      const int cid = cc * kMT_Cols + (site % kMT_Cols);
-      if (cid >= a.numCols) continue;
-      int p0, base;
-      mt_line(cid, a.H, a.strideMu, J, p0, base);
-      const int jmine = j0 + pos;
-      const int pmine = p0 ^ (jmine & 1), xmine = base + jmine * a.strideMu;
+      int pmine, xmine;
+      if constexpr (kRow) {
+        const int R = a.rowsPerTile, pr = site / EPR;
+        pmine = pr / R;
+        xmine = (blk * R + pr - pmine * R) * EPR + site - pr * EPR;
+      } else {
+        const int pos = site / kMT_Cols;
+        const int cid = cc * kMT_Cols + (site % kMT_Cols);
+        if (cid >= a.numCols) continue;
+        int p0, base;
+        mt_line(cid, a.H, a.strideMu, J, p0, base);
+        const int jmine = j0 + pos;
+        pmine = p0 ^ (jmine & 1);
+        xmine = base + jmine * a.strideMu;
+      }
       Cplx<double> full[16];
 #pragma unroll
       for (int e = 0; e < 16; e++) full[e] = scratch[e * kSites + site];
@@ -377,6 +440,21 @@ static int mfma_tile_tj(int extent, int kmax) {
   return 0;
 }
 
+// mu = x: R whole rows per workgroup, R X0 / 2 = 64 G entries per parity ... i.e. R X0 = 128 | 192 sites (G = 2 | 3 groups per wave)
+static bool mfma_row_geometry(const MugiqHipSpinorField &ev, int *groups, int *rows) {
+  const int epr = ev.X[0] / 2, nRows = ev.volumeCB / epr;
+  if (epr % 4 != 0) return false;
+  for (int g : {3, 2}) {
+    if ((32 * g) % epr != 0) continue;
+    const int r = 32 * g / epr;
+    if (nRows % r != 0 || r * 8 * (epr + 2) > 64 * kMT_Waves) continue;
+    *groups = g;
+    *rows = r;
+    return true;
+  }
+  return false;
+}
+
 // Can the axial-gauge tile take this entry?  fp64 FLOAT2 storage and loops, mu = y, z, t, lengths 1 .. Kmax (the gauge is
 // built from W_1 .. W_Kmax).  MUGIQ_HIP_TILE_MFMA = 0 switches it off (the vector tiles of csrc/fused_tile.hip /
 // fused_tile16.hip take over).
@@ -389,23 +467,37 @@ bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, const int *kva
     if (atoi(e) != 0) return false;  // a vector-tile generation was asked for by name
   if (const char *e = getenv("MUGIQ_HIP_TILE_GLDS"))
     if (atoi(e) == 0) return false;  // register-staged vector tile asked for
-  if (ev.precision != 8 || ev.field_order != 2 || dir < 1) return false;
+  if (ev.precision != 8 || ev.field_order != 2) return false;
   if (2 * (int64_t)ev.parity_offset >= (1LL << 31)) return false;  // the kernel keeps 32-bit element offsets
   for (int i = 0; i < nK; i++)
     if (kvals[i] != i + 1) return false;  // W_1 .. W_Kmax, all of them, in order
   const int kmax = nK;
   if (kmax > kMT_MaxSlots - 1 || kmax > ev.X[dir]) return false;
+  if (dir == 0) {  // whole x rows: no ghost handling
+    int g, r;
+    if (const char *e = getenv("MUGIQ_HIP_MFMA_ROW"))
+      if (atoi(e) == 0) return false;
+    return !partitioned && mfma_row_geometry(ev, &g, &r);
+  }
   return mfma_tile_tj(ev.X[dir], kmax) != 0;
 }
 
-static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, hipStream_t stream) {
+static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, int rowGroups, hipStream_t stream) {
   const int ln = tj == 4 ? 32 : 16;
-  const size_t shmem = std::max((size_t)2 * kMT_BufElems * sizeof(Cplx<double>), (size_t)16 * tj * ln * sizeof(Cplx<double>));
-  const unsigned nblocks = (unsigned)(((a.numCols + ln - 1) / ln) * a.jtCount);
+  const size_t shmem = std::max((size_t)2 * kMT_BufElems * sizeof(Cplx<double>), (size_t)16 * (dir == 0 ? 64 * rowGroups : tj * ln) * sizeof(Cplx<double>));
+  const unsigned nblocks = dir == 0 ? (unsigned)(a.numCols / a.rowsPerTile) : (unsigned)(((a.numCols + ln - 1) / ln) * a.jtCount);
   a.blockOrder = 2;
   if (const char *e = getenv("MUGIQ_HIP_TILE_ORDER")) a.blockOrder = atoi(e) & 2;
-  if (nblocks % 8 != 0) a.blockOrder = 0;
+  if (nblocks % 8 != 0 || dir == 0) a.blockOrder = 0;
   const dim3 grid(nblocks), block(64 * kMT_Waves);
+#define MUGIQ_MT_ROW(S, N)                                                                                             \
+  {                                                                                                                    \
+    if (rowGroups == 3) MUGIQ_MT_LAUNCH_(0, S, N, 0, 48) else MUGIQ_MT_LAUNCH_(0, S, N, 0, 32)                         \
+  }
+#define MUGIQ_MT_ROWCASE(S)                                                                                            \
+  case (S):                                                                                                            \
+    if (ns == 1) MUGIQ_MT_ROW(S, 1) else if (ns == 2) MUGIQ_MT_ROW(S, 2) else MUGIQ_MT_ROW(S, 3)                       \
+    break;
 #define MUGIQ_MT_LAUNCH(D, S, N)                                                                                       \
   {                                                                                                                    \
     if (tj == 12) MUGIQ_MT_LAUNCH_(D, S, N, 12, 16) else if (tj == 8) MUGIQ_MT_LAUNCH_(D, S, N, 8, 16) else MUGIQ_MT_LAUNCH_(D, S, N, 4, 32) \
@@ -421,6 +513,7 @@ static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, hipS
     if (ns == 1) MUGIQ_MT_LAUNCH(D, S, 1) else if (ns == 2) MUGIQ_MT_LAUNCH(D, S, 2) else if (ns == 3) MUGIQ_MT_LAUNCH(D, S, 3) else MUGIQ_MT_LAUNCH(D, S, 4) \
     break;
   switch (dir * 2 + sign) {
+    MUGIQ_MT_ROWCASE(0) MUGIQ_MT_ROWCASE(1)
     MUGIQ_MT_CASE(1, 0) MUGIQ_MT_CASE(1, 1) MUGIQ_MT_CASE(2, 0) MUGIQ_MT_CASE(2, 1) MUGIQ_MT_CASE(3, 0) MUGIQ_MT_CASE(3, 1)
   default:
     return set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "mfma tile: direction %d has no matrix-pipe tile (internal)", dir);
@@ -428,6 +521,8 @@ static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, hipS
 #undef MUGIQ_MT_CASE
 #undef MUGIQ_MT_LAUNCH
 #undef MUGIQ_MT_LAUNCH_
+#undef MUGIQ_MT_ROW
+#undef MUGIQ_MT_ROWCASE
   MUGIQ_CHECK_HIP(hipGetLastError());
   return MUGIQ_HIP_SUCCESS;
 }
@@ -459,7 +554,7 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
     a.X[d] = ev[0].X[d];
     if (d < dir) strideMu *= ev[0].X[d];
   }
-  strideMu /= 2;
+  strideMu = dir == 0 ? 1 : strideMu / 2;  // (unused by the row tile: a step along x is half a checkerboard entry)
   a.volumeCB = ev[0].volumeCB;
   a.stride = ev[0].stride;
   a.parity_offset = ev[0].parity_offset;
@@ -470,8 +565,18 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
   a.strideMu = (int)strideMu;
   a.H = (int)(ev[0].volumeCB / (ev[0].X[dir] * strideMu));
   a.numCols = 2 * ev[0].volumeCB / ev[0].X[dir];
-  const int tj = mfma_tile_tj(ev[0].X[dir], nK);
-  MUGIQ_REQUIRE(tj != 0, "mfma tile: no tile geometry for extent %d, lengths 1..%d (internal)", ev[0].X[dir], nK);
+  int tj = 0, rowGroups = 0;
+  a.rowsPerTile = a.rowChunk = 0;
+  if (dir == 0) {
+    MUGIQ_REQUIRE(mfma_row_geometry(ev[0], &rowGroups, &a.rowsPerTile), "mfma tile: no row geometry for X0 = %d (internal)", ev[0].X[0]);
+    a.rowChunk = (a.rowsPerTile * (ev[0].X[0] / 2 + 2) + 11) / 16 * 16 + 4;  // >= R (X0/2 + 2), and 4 mod 16 entries: 16 banks of phase per component
+    MUGIQ_REQUIRE(24 * a.rowChunk <= kMT_BufElems, "mfma tile: row image of %d entries per chunk does not fit (internal)", a.rowChunk);
+    ultra_d = nullptr;  // (the row tile takes no fourth slot)
+    tj = ev[0].X[0];    // one "tile" along mu
+  } else {
+    tj = mfma_tile_tj(ev[0].X[dir], nK);
+    MUGIQ_REQUIRE(tj != 0, "mfma tile: no tile geometry for extent %d, lengths 1..%d (internal)", ev[0].X[dir], nK);
+  }
   const int nJT = ev[0].X[dir] / tj;
   a.overwrite = (region & MUGIQ_HIP_REGION_OVERWRITE) ? 1 : 0;
   region &= 0xff;
@@ -492,6 +597,9 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
     g.H = a.H;
     g.numCols = a.numCols;
     g.volumeCB = a.volumeCB;
+    g.rowMode = dir == 0;
+    g.X1 = ev[0].X[1];
+    g.X2 = ev[0].X[2];
     hipLaunchKernelGGL(axial_gauge_kernel, dim3((a.numCols + 63) / 64), dim3(64), 0, stream, g);
     MUGIQ_CHECK_HIP(hipGetLastError());
     a.G = g.G;
@@ -523,7 +631,7 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
     }
   }
   if (a.jtCount > 0) {
-    st = launch_mfma_tile(a, dir, sign, ns, tj, stream);
+    st = launch_mfma_tile(a, dir, sign, ns, tj, rowGroups, stream);
     if (st) return st;
     if (withUltra && carried) *carried = 1;
   }
