@@ -54,8 +54,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-CLOCK_NOTE = ("peak = 78.6 TFLOP/s at 2.4 GHz; the device runs the tiled displaced kernels at 1.72-1.78 GHz (GRBM_GUI_ACTIVE / duration, "
-              "profiles/r02_kernel_clocks.txt): 56.7 TFLOP/s on offer at that clock")
+CLOCK_NOTE = ("flops = the reference's arithmetic per site, slot and eigenvector (W_k psi: 36 complex FMAs + colour-traced outer product: 48 = 672 flop); "
+              "peak = 78.6 TFLOP/s at 2.4 GHz.  The kernel itself (csrc/fused_mfma.hip) rotates the eigenvectors into an axial gauge once per staged "
+              "position instead of applying W_k per slot and runs the outer products on the fp64 matrix pipe: profiles/r04_mfma_tile.txt")
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # same guide: FP32 vector 157.3 TFLOP/s; fp64 FMA (vector and MFMA alike) runs at half of it
 ENTRIES_CFG2 = "+x:1,3;-x:1,3;+y:1,3;-y:1,3;+z:1,3;-z:1,3;+t:1,3;-t:1,3"
 
@@ -416,14 +417,17 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
         ms_f = phase_sum(ph, "entry_fused", i)
         if ms_f > 0:
             carries = best["carrier"] == i   # this entry's pass also produced the ultra-local loop: + 48 complex FMAs per site and eigenvector, + its slot
-            out["roofline"][tag] = roof("fp64_vector", ("tile16_displaced_contract_kernel<DIR=0> (row tile, 16-line items)" if e[0] == 0 else
-                                                        "tile_displaced_contract_kernel (column tile)" + (", 16 waves: + the ultra-local loop as a fourth slot" if carries else "")),
+            mfma = prec == 8 and e[2] == 1 and e[3] <= 3 and os.environ.get("MUGIQ_HIP_TILE_MFMA", "1") != "0"     # what csrc/fused.hip hands to csrc/fused_mfma.hip
+            out["roofline"][tag] = roof("fp64_vector", (("mfma_tile_displaced_contract_kernel (axial gauge + fp64 matrix pipe; " + ("whole x rows" if e[0] == 0 else "column tile")) if mfma else
+                                                        ("tile16_displaced_contract_kernel<DIR=0> (row tile, 16-line items" if e[0] == 0 else "tile_displaced_contract_kernel (column tile"))
+                                        + (") + the ultra-local loop as a fourth slot" if carries else ")"),
                                         ms_f, ent_bytes + (V * 32 * B if carries else 0), ent_flops + (V * nev * 48 * 8.0 if carries else 0), note=CLOCK_NOTE)
             if pmc_workload:
-                attach_traffic(out["roofline"][tag], ["displaced_contract_kernel<double, double, 2, %d, %d," % (e[0], e[1])])
+                attach_traffic(out["roofline"][tag], ["mfma_tile_displaced_contract_kernel<%d, %d," % (e[0], e[1])] if mfma else
+                               ["displaced_contract_kernel<double, double, 2, %d, %d," % (e[0], e[1])])
         else:
             ms_i, ms_b = phase_sum(ph, "entry_interior", i), phase_sum(ph, "entry_boundary", i)
-            out["roofline"][tag] = roof("fp64_vector", "tile_displaced_contract_kernel interior + boundary (partitioned axis)",
+            out["roofline"][tag] = roof("fp64_vector", "displaced contraction, interior + boundary tiles (partitioned axis)",
                                         ms_i + ms_b, ent_bytes, ent_flops)
             out["roofline"][tag].update({"interior_ms": ms_i, "boundary_ms": ms_b, "halo_wait_ms": phase_sum(ph, "halo_wait", i)})
     ms_u = phase_sum(ph, "ultra_local")

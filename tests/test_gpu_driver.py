@@ -725,6 +725,37 @@ def test_full_size_reflected_entries_agree_with_computed_ones(hip, monkeypatch):
     assert float((res["streaming"] - res["direct"]).abs().max()) < 1e-12 * scale
 
 
+def test_axial_gauge_matrix_pipe_tile_geometries(hip, monkeypatch):
+    """csrc/fused_mfma.hip: every tile geometry of the axial-gauge matrix-pipe kernel (4 x 32, 8 x 16, 12 x 16 sites for mu = y, z, t;
+    whole x rows for mu = x), both signs, one to three lengths, with and without the ultra-local loop riding along, against the
+    oracle -- and against the vector tiles of csrc/fused_tile.hip (MUGIQ_HIP_TILE_MFMA=0), which apply W_k per slot instead of
+    rotating the eigenvectors into the axial gauge once.  The lattice has a t extent every geometry divides."""
+    X, nev = (8, 8, 4, 24), 3
+    ev, Uo, f, U = _setup(hip, X, nev, 8, 2, 4242)
+    sg = sigmas(nev)
+    entry = "+t:1,3;-t:1,3;+x:1,3;-x:1,2;+y:1;-z:1,2"
+    _, s, a, b = orc.parse_disp_entry_string(entry)
+    ref = orc.compute_loop_position_space(ev, sg, orc.LoopComputeParam(s, a, b), Uo, X)
+    monkeypatch.setenv("MUGIQ_HIP_REFLECT", "0")            # every entry from the eigenvectors: both signs go through the kernels
+    settings = [{"MUGIQ_HIP_MFMA_TJ": "4"}, {"MUGIQ_HIP_MFMA_TJ": "8"}, {"MUGIQ_HIP_MFMA_TJ": "12"}, {"MUGIQ_HIP_MFMA_ROW": "0"},
+                {"MUGIQ_HIP_CARRY_ULTRALOCAL": "0"}, {"MUGIQ_HIP_TILE_MFMA": "0"}]
+    got = {}
+    for env in settings:
+        for k in ("MUGIQ_HIP_MFMA_TJ", "MUGIQ_HIP_MFMA_ROW", "MUGIQ_HIP_CARRY_ULTRALOCAL", "MUGIQ_HIP_TILE_MFMA"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        loop = hip.Loop_Mugiq(hip.MugiqLoopParam(gauge=U).set_displace_entry_string(entry), f, sg)
+        loop.computeCoarseLoop()
+        tag = "%s=%s" % next(iter(env.items()))
+        got[tag] = loop.dataPos_d.cpu().numpy()
+        assert rel_err(got[tag], ref) < 1e-12, tag
+        if "CARRY" not in tag and "TILE_MFMA" not in tag:
+            assert loop.ultraLocalCarrier() >= 0, tag          # an unpartitioned column entry took the ultra-local loop along
+        loop.close()
+    assert rel_err(got["MUGIQ_HIP_MFMA_TJ=8"], got["MUGIQ_HIP_TILE_MFMA=0"]) < 1e-13
+
+
 @pytest.mark.parametrize("X", [(2, 2, 4, 8), (2, 8, 8, 8)])
 def test_row_tile_on_the_smallest_x_extent(hip, X):
     """X0 = 2 (one checkerboard entry per x-row): found by the 2500-seed sweep -- the row tile computed zero tiles along x

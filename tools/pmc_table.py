@@ -18,6 +18,10 @@ def a(sub, grid, gb, what):
 a("loop_contract_kernel", V32, V32 * (200 * 192 + 256) / 1e9, "N_ev 200 x 192 B per site read once + 256 B written")
 a("tile16_displaced_contract_kernel<double, double, 2, 0", None, V48 * (nev * 192 + 3 * (192 + 256)) / 1e9,
   "eigenvectors once (N_ev %d) + 3 x (W_k 192 B read + slot 256 B written) per site" % nev)
+for d in (0, 1, 2, 3):
+    a("mfma_tile_displaced_contract_kernel<%d," % d, None, V48 * (nev * 192 + 144 * (1 + 3 / (48 if d < 2 else 24)) + 3 * 256 + (256 if d == 1 else 0)) / 1e9,
+      "eigenvectors once (N_ev %d) + the axial gauge (144 B per staged position) + 3 slots x 256 B written" % nev + (" + the carried ultra-local slot" if d == 1 else ""))
+a("axial_gauge_kernel", None, V48 * (192 + 144 * (1 + 3 / 24)) / 1e9, "W_1 once (the W_k of the continued positions are a boundary term) + g written")
 for d in (1, 2, 3):
     a("tile_displaced_contract_kernel<double, double, 2, %d" % d, None, V48 * (nev * 192 + 3 * (192 + 256) + (256 if d == 1 else 0)) / 1e9,
       "as above" + (" + the carried ultra-local slot (256 B written)" if d == 1 else ""))
