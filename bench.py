@@ -77,7 +77,7 @@ def parse():
     ap.add_argument("--no-extra", action="store_true",
                     help="only the headline (use this under `rocprofv3 --stats`: the extra legs launch the headline kernel with "
                          "other shapes and would blur its per-kernel average)")
-    ap.add_argument("--extra", default="", help="comma list restricting the extra legs: displaced,forced,strong,mg,cfg3 (N=1) / partitioned,strong (N>1)")
+    ap.add_argument("--extra", default="", help="comma list restricting the extra legs: displaced,forced,strong,mg,cfg3 (N=1) / strong,partitioned,native (N>1)")
     ap.add_argument("--displaced-nev", type=int, default=400, help="eigenvectors of the displaced extra legs (configs[2]: 400 = 102 GB; 100 for a quick run)")
     ap.add_argument("--strong-nev", type=int, default=48, help="eigenvectors of the strong-scaling leg (48^3 x 96 on every N; 48 fit one GPU "
                                                               "next to all 25 position-space slots with room to spare: 98 + 68 GB; 64 is the most that fits)")
@@ -686,6 +686,9 @@ def extra_strong(hip, device, a, world, rank, backend):
     out["grid"], out["local_lattice"], out["n_ev"] = list(grid), list(X), nev
     out["global_sites"] = int(np.prod(G))
     out["seconds_1gpu"] = out["seconds"] if world == 1 else None
+    if world > 1:
+        one = dist_bcast_reference(one, mom, device, backend, rank)
+        _STRONG_REF.update({"mom": one["_mom"], "seconds": one["seconds"], "grid": grid, "G": G, "X": X, "nev": nev})
     if one is not None:
         out["seconds_1gpu"] = one["seconds"]
         out["speedup"] = one["seconds"] / out["seconds"]
@@ -727,6 +730,8 @@ def _leg_summary(rec):
     if blocks:
         heavy = max(blocks, key=lambda b: b["kernel_ms"])        # the block that takes the most time
         o.update({"top_kernel_ms": heavy["kernel_ms"], "top_frac": heavy["frac"], "top_bound": heavy["bound"]})
+    if "skipped" in rec:
+        return {"skipped": str(rec["skipped"])[:80]}
     for k in ("max_rel_diff_forced_vs_unpartitioned", "max_rel_diff_emulated_vs_unpartitioned", "max_rel_diff_vs_1gpu", "parity_ok"):
         if k in rec:
             o[k] = rec[k]
@@ -758,6 +763,9 @@ def compact_line(out, detail_path):
     if pt:
         line["partitioned"] = {k: pt[k] for k in ("local_lattice", "n_ev", "seconds", "sites_per_s_all_slots", "halo_bytes_sent_per_rank",
                                                   "halo_GBps_per_rank", "wait_ms_not_hidden") if pt.get(k) is not None}
+    nt = (out.get("also_measured") or {}).get("native_rccl_transport")
+    if isinstance(nt, dict) and "seconds" in nt:
+        line["native_rccl"] = {k: nt[k] for k in ("seconds", "speedup", "max_rel_diff_vs_1gpu") if nt.get(k) is not None}
     also = out.get("also_measured")
     if also:
         line["legs"] = {k: (_leg_summary(v) if isinstance(v, dict) else str(v)[:160]) for k, v in also.items()}
@@ -772,6 +780,46 @@ def compact_line(out, detail_path):
         text = json.dumps(line, allow_nan=False)
     assert "\n" not in text
     return text
+
+
+_STRONG_REF = {}
+
+
+def dist_bcast_reference(one, mom, device, backend, rank):
+    """rank 0's one-GPU result (seconds, momentum-space loops) to every rank, so that each can check what it holds"""
+    import torch.distributed as dist
+    wire = device if backend == "nccl" else "cpu"
+    t = torch.from_numpy(np.ascontiguousarray(one["_mom"] if rank == 0 else np.zeros_like(mom))).view(torch.float64).to(wire)
+    dist.broadcast(t, src=0)
+    sec = torch.tensor([one["seconds"] if rank == 0 else 0.0], dtype=torch.float64, device=wire)
+    dist.broadcast(sec, src=0)
+    if rank != 0:
+        one = {"seconds": float(sec[0]), "phase_ms": {}}
+    one["_mom"] = t.cpu().numpy().view(np.complex128).reshape(mom.shape)
+    return one
+
+
+def extra_native(hip, device, a, world, rank, backend):
+    """The strong-scaling job once more with the halos, the gauge borders and the momentum-space reductions on the library's OWN
+    transport (csrc/comm_rccl.cpp: ncclSend / ncclRecv groups on the halo stream, ncclReduce / AllGather / Broadcast over
+    ncclCommSplit sub-communicators; no Python callback in the data path) instead of torch.distributed.  Runs last: it has been on
+    hardware with one rank only, and a failure here must not cost the other legs."""
+    if backend != "nccl":
+        return {"skipped": "the native transport is RCCL: one device per rank (backend %s here)" % backend}
+    if not _STRONG_REF:
+        return {"skipped": "no strong-scaling reference in this run"}
+    r = _STRONG_REF
+    comm = hip.RcclComm(r["grid"], device=device)
+    out = displaced_job(hip, device, r["X"], r["nev"], 8, comm, world, reps=1, backend=backend, hashed=True)
+    mom = out.pop("_mom")
+    comm.close()
+    out["workload"] = "the strong-scaling job (48x48x48x96 global, N_ev=%d) on mugiq_hip_rccl_comm_create's transport" % r["nev"]
+    out["grid"], out["local_lattice"], out["n_ev"] = list(r["grid"]), list(r["X"]), r["nev"]
+    out["seconds_1gpu"] = r["seconds"]
+    out["speedup"] = r["seconds"] / out["seconds"]
+    out["max_rel_diff_vs_1gpu"] = max_rel_diff(mom, r["mom"])
+    out["parity_ok"] = bool(out["max_rel_diff_vs_1gpu"] < PARITY_TOL)
+    return out
 
 
 # ---- main --------------------------------------------------------------------------------------------------------------
@@ -957,7 +1005,8 @@ def main():
                  ("mg_coarse_loop", "mg", lambda: extra_mg(hip, device)),
                  ("cfg3_mixed_precision_ultra_local", "cfg3", lambda: extra_cfg3(hip, device))] if world == 1 else
                 [("strong_scaling_displaced_loops", "strong", lambda: extra_strong(hip, device, a, world, rank, backend)),     # the speedup first
-                 ("partitioned_displaced_loops", "partitioned", lambda: extra_partitioned(hip, device, a, world, rank, backend))])
+                 ("partitioned_displaced_loops", "partitioned", lambda: extra_partitioned(hip, device, a, world, rank, backend)),
+                 ("native_rccl_transport", "native", lambda: extra_native(hip, device, a, world, rank, backend))])
         also = {}
         out["also_measured"] = also
 

@@ -407,6 +407,26 @@ typedef struct MugiqHipComm_s {
   int partitioned[4];
 } MugiqHipComm;
 
+/* ---- a transport inside the library: the table above served by RCCL (csrc/comm_rccl.cpp) ---------------------------------
+ * ncclSend / ncclRecv on the caller's stream inside ncclGroupStart / End for the halos (different neighbours = different xGMI
+ * links at once), ncclReduce / ncclAllGather / ncclBroadcast over sub-communicators of the world one (ncclCommSplit) for the
+ * COMM_SPACE / COMM_TIME steps of lib/loop_mugiq.cpp:61-88, 406-424 (host payloads staged through device buffers).  librccl is
+ * loaded on first use.  Rank <-> coordinate map: QUDA's default (x slowest, t fastest).  One process per GPU; the device the
+ * communicator lives on is the current device at creation.
+ *   rank 0:        mugiq_hip_rccl_get_unique_id(id)           then hand the 128 bytes to every rank (MPI_Bcast, a file, a socket)
+ *   every rank:    mugiq_hip_rccl_comm_create(&rc, id, rank, size, grid, partitioned)     (collective: ncclCommInitRank + 2 splits)
+ *                  mugiq_hip_rccl_comm_fill(rc, &comm)        `comm` then goes wherever a MugiqHipComm goes
+ *                  ...                                        mugiq_hip_rccl_comm_destroy(rc) once no loop object uses `comm` any more
+ * A host that has an ncclComm_t already wraps it with mugiq_hip_rccl_comm_from_nccl (the communicator stays the host's).
+ * `partitioned` as MugiqHipComm.partitioned (NULL = none).  Verified on hardware with one rank only (self-neighbour halos through
+ * ncclSend / ncclRecv, tests/test_gpu_nccl.py): the pool this was built on has one GPU per box. */
+typedef struct MugiqHipRcclComm_s MugiqHipRcclComm;
+int mugiq_hip_rccl_get_unique_id(void *id128_out);
+int mugiq_hip_rccl_comm_create(MugiqHipRcclComm **out, const void *id128, int rank, int size, const int grid[4], const int partitioned[4]);
+int mugiq_hip_rccl_comm_from_nccl(MugiqHipRcclComm **out, void *ncclComm_world, const int grid[4], const int partitioned[4]);
+int mugiq_hip_rccl_comm_fill(MugiqHipRcclComm *c, MugiqHipComm *out);
+int mugiq_hip_rccl_comm_destroy(MugiqHipRcclComm *c);
+
 /* exchangeGhostVec(ColorSpinorField *x), lib/contract_wrappers.cu:166-169 (x->exchangeGhost(QUDA_INVALID_PARITY, nFace = 1, 0)):
  * fill the depth-1 ghost zones v->ghost[d][0 | 1] of every partitioned dimension (comm->grid[d] > 1 or comm->partitioned[d]), both directions,
  * through comm->sendrecv (one transfer group when the transport has group_begin / group_end).  The zones must be device

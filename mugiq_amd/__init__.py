@@ -19,7 +19,7 @@ from .loop import (  # noqa: E402
     MugiqLoopParam, Loop_Mugiq, parseDisplaceEntryString, parseDisplacement, read_momenta_file, writeLoopsHDF5_Mom, reflectMomentumSpace,
     LOOP_CALC_TYPE_BLAS, LOOP_CALC_TYPE_OPT_KERNEL, LOOP_CALC_TYPE_BASIC_KERNEL,
 )
-from .comm import GridComm  # noqa: E402
+from .comm import GridComm, RcclComm  # noqa: E402
 from .displace import Displace, DISPLACE_TYPE_COVARIANT  # noqa: E402
 
 __all__ = [n for n in dir() if not n.startswith("_")]

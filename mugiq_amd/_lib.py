@@ -87,6 +87,11 @@ SIGNATURES = {
                                                                        _I4, _VP]),
     "mugiq_hip_pack_face": (ctypes.c_int, [_VP, _SP, ctypes.c_int, ctypes.c_int, _VP]),
     "mugiq_hip_exchange_ghost_vec": (ctypes.c_int, [_SP, _VP, _VP]),
+    "mugiq_hip_rccl_get_unique_id": (ctypes.c_int, [_VP]),
+    "mugiq_hip_rccl_comm_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _VP, ctypes.c_int, ctypes.c_int, _I4, _I4]),
+    "mugiq_hip_rccl_comm_from_nccl": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _VP, _I4, _I4]),
+    "mugiq_hip_rccl_comm_fill": (ctypes.c_int, [_VP, _VP]),
+    "mugiq_hip_rccl_comm_destroy": (ctypes.c_int, [_VP]),
     "mugiq_hip_alloc_spinor_like": (ctypes.c_int, [_SP, _SP, ctypes.c_int, _I4]),
     "mugiq_hip_free_spinor": (ctypes.c_int, [_SP]),
     "mugiq_hip_copy_spinor": (ctypes.c_int, [_SP, _SP, _VP]),

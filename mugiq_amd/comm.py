@@ -287,3 +287,62 @@ class GridComm:
         c.sendrecv, c.reduce_space, c.gather_time, c.bcast, c.group_begin, c.group_end = fns
         self._cb = (c, fns)          # keep the callbacks alive
         return c
+
+
+class _CCommRaw(ctypes.Structure):
+    """MugiqHipComm with the callbacks as raw pointers (filled in by the library itself)"""
+    _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("size", ctypes.c_int),
+                ("grid", ctypes.c_int * 4), ("coord", ctypes.c_int * 4),
+                ("sendrecv", ctypes.c_void_p), ("reduce_space", ctypes.c_void_p), ("gather_time", ctypes.c_void_p), ("bcast", ctypes.c_void_p),
+                ("group_begin", ctypes.c_void_p), ("group_end", ctypes.c_void_p), ("partitioned", ctypes.c_int * 4)]
+
+
+class RcclComm:
+    """The library's own RCCL transport (csrc/comm_rccl.cpp: ncclSend / ncclRecv groups on the halo stream, ncclReduce / AllGather /
+    Broadcast over ncclCommSplit sub-communicators) behind the face of GridComm -- no Python in the data path; what a C++ host gets
+    from mugiq_hip_rccl_comm_create.  One process: nothing else is needed.  Several: torch.distributed (any backend) must be
+    initialised -- it only carries the 128-byte ncclUniqueId from rank 0 to the others; every rank must construct this (collective)."""
+
+    def __init__(self, grid, device=None, force_partitioned=(0, 0, 0, 0)):
+        lib = _lib.load()
+        self.grid = tuple(int(g) for g in grid)
+        self.force_partitioned = tuple(1 if f else 0 for f in force_partitioned)
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if dist.is_initialized():
+            self.size, self.rank = dist.get_world_size(), dist.get_rank()
+        else:
+            self.size, self.rank = 1, 0
+        assert int(np.prod(self.grid)) == self.size, "process grid %s does not match world size %d" % (self.grid, self.size)
+        uid = (ctypes.c_ubyte * 128)()
+        if self.rank == 0:
+            _lib.check(lib.mugiq_hip_rccl_get_unique_id(ctypes.cast(uid, ctypes.c_void_p)))
+        if self.size > 1:
+            wire = self.device if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = torch.tensor(list(uid), dtype=torch.uint8, device=wire)
+            dist.broadcast(t, src=0)
+            uid = (ctypes.c_ubyte * 128)(*t.cpu().tolist())
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.mugiq_hip_rccl_comm_create(ctypes.byref(self._h), ctypes.cast(uid, ctypes.c_void_p), self.rank, self.size,
+                                                      _lib.int4(self.grid), _lib.int4(self.force_partitioned)))
+        self._c = _CCommRaw()
+        _lib.check(lib.mugiq_hip_rccl_comm_fill(self._h, ctypes.byref(self._c)))
+        self.coord = tuple(self._c.coord)
+        self.backend = "rccl-native"
+
+    def comm_dim_partitioned(self, d):
+        return 1 if (self.grid[d] > 1 or self.force_partitioned[d]) else 0
+
+    def c_struct(self):
+        return self._c
+
+    def close(self):
+        if self._h:
+            _lib.load().mugiq_hip_rccl_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -338,3 +338,41 @@ def forced_full_size_worker(rank, world, port, X, nev, force, backend):
     assert float(np.abs(b_mom - o_mom).max()) / float(np.abs(o_mom).max()) < 1e-12
     dist.barrier()
     dist.destroy_process_group()
+
+
+def native_rccl_worker(rank, world, port):
+    """one rank, the library's own RCCL transport, forced partitioning on z and t; against the unpartitioned run and GridComm"""
+    import torch
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import mugiq_amd as hip
+    from bench import make_evecs, make_gauge, momenta_p2_le
+    X, nev = (8, 8, 8, 8), 4
+    _, f = make_evecs(hip, X, nev, 8, 2, dev, seed=5)
+    sg = 0.01 + 0.002 * np.arange(nev)
+    moms = momenta_p2_le(2)
+    entries = "+z:1,3;-z:1,3;+t:1,2;-t:2,3;+x:1,2;-y:1"
+
+    def run(gauge, comm):
+        prm = hip.MugiqLoopParam(gauge=gauge, doMomProj=True, momMatrix=moms, Nmom=len(moms), FTSign=-1).set_displace_entry_string(entries)
+        loop = hip.Loop_Mugiq(prm, f, sg, comm).setProfiling()
+        loop.computeCoarseLoop()
+        out = loop.dataPos_d.clone(), np.array(loop.dataMom_global()), set(p["kind"] for p in loop.phases())
+        loop.close()
+        return out
+
+    ref_pos, ref_mom, _ = run(make_gauge(hip, X, 8, dev, 321, None), None)
+    native = hip.RcclComm((1, 1, 1, 1), device=dev, force_partitioned=(0, 0, 1, 1))
+    assert native.comm_dim_partitioned(3) == 1 and native.coord == (0, 0, 0, 0) and native.c_struct().sendrecv
+    g_native = make_gauge(hip, X, 8, dev, 321, native)            # borders R = 2 through the native sendrecv
+    pos, mom, kinds = run(g_native, native)
+    assert {"halo_transfer", "entry_interior", "entry_boundary"} <= kinds, kinds
+    scale = float(ref_pos.abs().max())
+    assert float((pos - ref_pos).abs().max()) < 1e-13 * scale
+    assert float(np.abs(mom - ref_mom).max()) < 1e-12 * float(np.abs(ref_mom).max())
+    grid = hip.GridComm((1, 1, 1, 1), device=dev, force_partitioned=(0, 0, 1, 1))
+    g_grid = make_gauge(hip, X, 8, dev, 321, grid)
+    assert torch.equal(g_grid.data, g_native.data), "gauge borders differ between the two transports"
+    pos2, mom2, _ = run(g_grid, grid)
+    assert torch.equal(pos2, pos), "loops differ between the native and the torch transport"
+    native.close()
