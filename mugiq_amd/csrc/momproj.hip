@@ -300,8 +300,9 @@ template <typename F> struct EoStager {
   int wv, rpw, groups, nRuns, tStride, base, dstBase, parBase, tpLane, ld, run, volumeCB;
   vec2 u[kEoLd];
 
+  // a tile holds the time slices [t0, t0 + a.tChunk) of a y pair (all of them when tChunk == Lt)
   __device__ inline void init(const EoDftArgs<F> &a, int z) {
-    const int Lx = a.X[0], Ly = a.X[1], Lz = a.X[2], Lt = a.X[3];
+    const int Lx = a.X[0], Ly = a.X[1], Lz = a.X[2], Lt = a.tChunk;
     ld = Lx + 1;
     const int hx = Lx >> 1;
     run = kEoYG * hx;
@@ -331,8 +332,8 @@ template <typename F> struct EoStager {
     pty = tp & 1;
     t = tp >> 1;
   }
-  __device__ inline void fetch(const Cplx<F> *src, int ty) {
-    const Cplx<F> *sp = src + (int64_t)ty * run + base;  // rows y0 = kEoYG * ty: run = kEoYG * Lx / 2 entries further
+  __device__ inline void fetch(const Cplx<F> *src, int ty, int t0 = 0) {
+    const Cplx<F> *sp = src + (int64_t)ty * run + base + (int64_t)t0 * tStride;  // rows y0 = kEoYG * ty: run = kEoYG * Lx / 2 entries further
     asm volatile("" : "+v"(tpLane));
 #pragma unroll
     for (int q = 0; q < kEoLd; q++) {
@@ -341,13 +342,13 @@ template <typename F> struct EoStager {
       MUGIQ_EO_LOAD(u[q], sp + (pty_ * volumeCB + t_ * tStride))
     }
   }
-  __device__ inline void commit(Cplx<F> *tile, F sign) {
+  __device__ inline void commit(Cplx<F> *tile, F sign, int t0 = 0) {
     asm volatile("" : "+v"(tpLane));
 #pragma unroll
     for (int q = 0; q < kEoLd; q++) {
       int pty_, t_;
       slot(q, pty_, t_);
-      tile[dstBase + t_ * ld + ((pty_ - (parBase + t_)) & 1)] = Cplx<F>{sign * u[q].x, sign * u[q].y};
+      tile[dstBase + t_ * ld + ((pty_ - (parBase + t0 + t_)) & 1)] = Cplx<F>{sign * u[q].x, sign * u[q].y};
     }
   }
 };
@@ -365,15 +366,16 @@ template <typename F> __global__ __launch_bounds__(256) void eo_dft_x_pipelined_
   const Cplx<F> *src = a.in + (int64_t)idataFrom * 2 * a.volumeCB;
   EoStager<F> st;
   st.init(a, z);
-  const int tiles = a.X[1] / kEoYG;
+  const int nCh = a.X[3] / a.tChunk, tiles = (a.X[1] / kEoYG) * nCh;  // tile tt = (y pair tt / nCh, time chunk tt % nCh)
   const int tb = blockIdx.x * a.tilesPerWg, te = tb + a.tilesPerWg < tiles ? tb + a.tilesPerWg : tiles;
-  if (tb < te) st.fetch(src, tb);
-  for (int ty = tb; ty < te; ty++) {
+  if (tb < te) st.fetch(src, tb / nCh, (tb % nCh) * a.tChunk);
+  for (int tt = tb; tt < te; tt++) {
+    const int t0 = (tt % nCh) * a.tChunk;
     __syncthreads();  // the previous tile's sums and stores are done with the LDS
-    st.commit(tile, sign);
-    if (ty + 1 < te) st.fetch(src, ty + 1);
+    st.commit(tile, sign, t0);
+    if (tt + 1 < te) st.fetch(src, (tt + 1) / nCh, ((tt + 1) % nCh) * a.tChunk);
     __syncthreads();
-    eo_dft_x_sums(a, tile, ty * kEoYG, z, idataTo, 0, a.X[3]);
+    eo_dft_x_sums(a, tile, (tt / nCh) * kEoYG, z, idataTo, t0, a.tChunk);
   }
 }
 
@@ -392,7 +394,7 @@ template <int NKS, int MB> __global__ __launch_bounds__(256) void eo_dft_x_mfma_
   typedef double d4 __attribute__((ext_vector_type(4)));
   extern __shared__ __align__(16) unsigned char smem[];
   Cplx<double> *tile = reinterpret_cast<Cplx<double> *>(smem);
-  const int Lx = a.X[0], Ly = a.X[1], Lt = a.X[3], ld = Lx + 1;
+  const int Lx = a.X[0], Ly = a.X[1], Lt = a.X[3], tn = a.tChunk, ld = Lx + 1;
   const int z = blockIdx.y;
   int ig, idataFrom, idataTo;
   eo_dft_channels(a, ig, idataFrom, idataTo);
@@ -401,7 +403,7 @@ template <int NKS, int MB> __global__ __launch_bounds__(256) void eo_dft_x_mfma_
   EoStager<double> st;
   st.init(a, z);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int rows = kEoYG * Lt, xw = wave * (Lx >> 2);  // NKS = Lx / 8 k-steps per wave, MB = ceil(rows / 16) row blocks: compile
+  const int rows = kEoYG * tn, xw = wave * (Lx >> 2);  // NKS = Lx / 8 k-steps per wave, MB = ceil(rows / 16) row blocks: compile
                                                        // time, so the tile loop is straight-line code (with run-time bounds
                                                        // every MFMA sat in its own basic block behind its own LDS wait)
   const int kq = lane >> 4, col = lane & 15;
@@ -421,13 +423,14 @@ template <int NKS, int MB> __global__ __launch_bounds__(256) void eo_dft_x_mfma_
     const int row = 16 * mb + col < rows ? 16 * mb + col : rows - 1;
     aoff[mb] = (row * ld + xw + (kq >> 1)) * 2 + (kq & 1);
   }
-  const int tiles = Ly / kEoYG;
+  const int nCh = Lt / tn, tiles = (Ly / kEoYG) * nCh;  // tile tt = (y pair tt / nCh, time chunk tt % nCh)
   const int tb = blockIdx.x * a.tilesPerWg, te = tb + a.tilesPerWg < tiles ? tb + a.tilesPerWg : tiles;
-  if (tb < te) st.fetch(src, tb);
-  for (int ty = tb; ty < te; ty++) {
+  if (tb < te) st.fetch(src, tb / nCh, (tb % nCh) * tn);
+  for (int tt = tb; tt < te; tt++) {
+    const int ty = tt / nCh, t0 = (tt % nCh) * tn;
     __syncthreads();  // the previous tile's partial products have been consumed
-    st.commit(tile, sign);
-    if (ty + 1 < te) st.fetch(src, ty + 1);
+    st.commit(tile, sign, t0);
+    if (tt + 1 < te) st.fetch(src, (tt + 1) / nCh, ((tt + 1) % nCh) * tn);
     __syncthreads();
     const double *td = reinterpret_cast<const double *>(tile);
     d4 acc[MB];
@@ -451,7 +454,7 @@ template <int NKS, int MB> __global__ __launch_bounds__(256) void eo_dft_x_mfma_
     __syncthreads();
     const int y0 = ty * kEoYG;
     for (int o = threadIdx.x; o < rows * a.nPx; o += 256) {
-      const int t = o % Lt, rest = o / Lt, j = rest % a.nPx, yy = rest / a.nPx, row = yy * Lt + t;
+      const int t = o % tn, rest = o / tn, j = rest % a.nPx, yy = rest / a.nPx, row = yy * tn + t;
       Cplx<double> s{0.0, 0.0};
 #pragma unroll
       for (int w = 0; w < 4; w++) {  // fixed order: x ranges 0, 1, 2, 3
@@ -459,7 +462,7 @@ template <int NKS, int MB> __global__ __launch_bounds__(256) void eo_dft_x_mfma_
         s.re += q[0];
         s.im += q[1];
       }
-      a.out[((int64_t)(z * Ly + y0 + yy) * a.nPx + j) * a.M + t + Lt * idataTo] = s;
+      a.out[((int64_t)(z * Ly + y0 + yy) * a.nPx + j) * a.M + t0 + t + Lt * idataTo] = s;
     }
   }
 }
@@ -533,8 +536,14 @@ int eo_dft_x_time_chunk(int precision, const int localL[4], int nPx) {
     }
   }
   if (tcMax == 0) return 0;
+  // the largest chunk that divides Lt and that the pipelined forms can stage (4 waves x kEoLd loads cover its 2 tc runs) ...
+  const int run = kEoYG * localL[0] / 2, rpw = run <= 64 ? 64 / run : 0;
+  if (rpw)
+    for (int tc = tcMax; tc >= 1; tc--)
+      if (localL[3] % tc == 0 && (2 * tc + rpw - 1) / rpw <= 4 * kEoLd) return tc;
+  // ... else even chunks for the general kernel
   const int nChunks = (localL[3] + tcMax - 1) / tcMax;
-  return (localL[3] + nChunks - 1) / nChunks;  // even chunks
+  return (localL[3] + nChunks - 1) / nChunks;
 }
 
 // the plan: distinct p_x, distinct (p_x, p_y) pairs, and the tables of the three steps
@@ -711,15 +720,17 @@ static int launch_separable(void *C, const void *A, const void *dataPosEO, int n
     e.nPx = (int)P.px.size();
     e.M = M;
     e.slotMap = slotMap_h ? int_d + slotOff : nullptr;
-    const int run = kEoYG * localL[0] / 2, tiles = localL[1] / kEoYG;
-    const bool pipelined = tChunk == localL[3] && run <= 64 && (2 * localL[3] + 64 / run - 1) / (64 / run) <= 4 * kEoLd;
+    // the pipelined forms walk tiles = (y pair, chunk of time slices): whole time slabs when they fit the LDS, else even chunks
+    const int nCh = localL[3] % tChunk == 0 ? localL[3] / tChunk : 0;
+    const int run = kEoYG * localL[0] / 2, tiles = (localL[1] / kEoYG) * std::max(nCh, 1);
+    const bool pipelined = nCh >= 1 && run <= 64 && (2 * tChunk + 64 / run - 1) / (64 / run) <= 4 * kEoLd;
     // the sums on the matrix pipe where it applies (fp64; one pass: <= 64 rows, <= 8 distinct p_x; Lx = 24, 32, 48 or 64):
     // 1.95 ms against 2.06 ms for the vector form at 48.48.24.24 x 25 slots (profiles/r02_eo_dft_x_kernel_stats_*.csv);
     // MUGIQ_HIP_EO_MFMA = 0 keeps the vector form
     bool mfma = true;
     if (const char *m = getenv("MUGIQ_HIP_EO_MFMA")) mfma = atoi(m) != 0;
-    const int mfmaKs = localL[0] / 8, mfmaMb = (kEoYG * localL[3] + 15) / 16;
-    mfma = mfma && sizeof(F) == 8 && pipelined && kEoYG * localL[3] <= 64 && (int)P.px.size() <= 8 && localL[0] % 8 == 0 &&
+    const int mfmaKs = localL[0] / 8, mfmaMb = (kEoYG * tChunk + 15) / 16;
+    mfma = mfma && sizeof(F) == 8 && pipelined && kEoYG * tChunk <= 64 && (int)P.px.size() <= 8 && localL[0] % 8 == 0 &&
            (mfmaKs == 3 || mfmaKs == 4 || mfmaKs == 6 || mfmaKs == 8) && mfmaMb >= 2;
     if (pipelined) {
       // about 32 workgroups per CU (8 rounds of 4): enough to balance, few enough to amortise the pipeline fill
@@ -744,7 +755,7 @@ static int launch_separable(void *C, const void *A, const void *dataPosEO, int n
     } else {
       e.tilesPerWg = 1;
       const int nChunks = (localL[3] + tChunk - 1) / tChunk;
-      hipLaunchKernelGGL((eo_dft_x_kernel<F>), dim3(tiles * nChunks, localL[2], nData), dim3(256), shmem, stream, e);
+      hipLaunchKernelGGL((eo_dft_x_kernel<F>), dim3((localL[1] / kEoYG) * nChunks, localL[2], nData), dim3(256), shmem, stream, e);
     }
     MUGIQ_CHECK_HIP(hipGetLastError());
     firstStep = 1;
