@@ -275,7 +275,8 @@ def test_four_rank_driver_extent_four_grid_on_one_gpu(grid, G, prec, order, calc
 
 
 def test_driver_writes_reference_hdf5_tree(hip, tmp_path):
-    """computeLoop -> writeLoopsHDF5 (lib/interface_mugiq.cpp:158-172): file contents == dataMom_bcast."""
+    """computeLoop -> writeLoopsHDF5 (lib/interface_mugiq.cpp:158-172): the file holds, group by group, the numbers the ORACLE gets for
+    the same job (position-space loops -> reorder + gamma5 map -> projection), and they are bit for bit dataMom_bcast."""
     import h5read
     try:
         h5 = h5read.H5()
@@ -293,6 +294,15 @@ def test_driver_writes_reference_hdf5_tree(hip, tmp_path):
     loop.computeCoarseLoop()
     loop.writeLoopsHDF5()
     mom = loop.dataMom_global()                               # [Nmom][nLoop][16][totT]
+    # the oracle's momentum-space loops of the same job
+    _, ds, da, db = orc.parse_disp_entry_string("-t:1,2;+y:2")
+    cprm = orc.LoopComputeParam(ds, da, db)
+    pos = orc.compute_loop_position_space(ev, sigmas(3), cprm, Uo, X)
+    V, locV3 = int(np.prod(X)), X[0] * X[1] * X[2]
+    mp_ = orc.convert_idx_order_map_gamma(pos, cprm.nData, cprm.nLoop, 2, V // 2, X)
+    ref = orc.momentum_projection_local(mp_, orc.phase_matrix(moms, locV3, 1, X, X), X[3], cprm.nData, locV3, len(moms))
+    ref = np.asarray(ref).reshape(len(moms), cprm.nLoop, 16, X[3])
+    scale = np.max(np.abs(ref))
     fid = h5.open(fn)
     names = ["disp_0", "disp_-t_1", "disp_-t_2", "disp_+y_2"]
     for im, p in enumerate(moms):
@@ -300,6 +310,7 @@ def test_driver_writes_reference_hdf5_tree(hip, tmp_path):
             for ig in range(16):
                 got = h5.read(fid, "/mom_%+d_%+d_%+d/%s/%s/loop" % (p + (dn, hip.GammaName(ig))))
                 assert np.array_equal(got[:, 0] + 1j * got[:, 1], mom[im, iL, ig])
+                assert np.max(np.abs(got[:, 0] + 1j * got[:, 1] - ref[im, iL, ig])) < 1e-12 * scale, (p, dn, ig)
     h5.close(fid)
     loop.close()
     # position-space output is "Not supported yet!" in the reference too
