@@ -517,14 +517,18 @@ def extra_forced(hip, device, nev=400, emulate_GBps=0.0):
         # same eigenvectors, same links (seed), same momenta: the partitioned code path must give the unpartitioned numbers
         out["max_rel_diff_forced_vs_unpartitioned"] = max_rel_diff(mom, ref)
         out["parity_ok"] = bool(out["max_rel_diff_forced_vs_unpartitioned"] < PARITY_TOL)
-    out["workload"] = "48x48x24x24 fp64 N_ev=%d, z and t FORCED-partitioned on one rank (self-neighbour: device copies, no xGMI), " \
+    out["workload"] = "48x48x24x24 fp64 N_ev=%d, z and t FORCED-partitioned on one rank (self-neighbour: face layers packed straight into the ghost buffers, no xGMI), " \
                       "entries %s, momentum projection p^2<=9, driver OPT plan, halos posted ahead" % (nev, ENTRIES_CFG2)
     out["forced_partition"] = [0, 0, 1, 1]
     if emulate_GBps > 0:
         # the same job once more with the self-messages slowed down to the pace of an xGMI link (see GridComm): what the schedule
         # hides and what it does not when the halo takes as long as it would between GPUs
         comm2 = hip.GridComm((1, 1, 1, 1), device=device, force_partitioned=(0, 0, 1, 1), emulate_link_GBps=emulate_GBps)
-        emu = displaced_job(hip, device, X, nev, 8, comm2, 1, reps=1, fields=fields, gauge=gauge)
+        os.environ["MUGIQ_HIP_SELF_HALO_COPY"] = "1"      # the messages to self are copies again (default: packed in place), so that they can be paced
+        try:
+            emu = displaced_job(hip, device, X, nev, 8, comm2, 1, reps=1, fields=fields, gauge=gauge)
+        finally:
+            os.environ.pop("MUGIQ_HIP_SELF_HALO_COPY", None)
         emom = emu.pop("_mom")
         if ref is not None:
             out["max_rel_diff_emulated_vs_unpartitioned"] = max_rel_diff(emom, ref)

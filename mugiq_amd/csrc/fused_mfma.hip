@@ -527,6 +527,48 @@ static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, int 
   return MUGIQ_HIP_SUCCESS;
 }
 
+namespace {
+struct AxialHint {
+  const void *G = nullptr, *E1 = nullptr;
+  int dir = -1, sign = -1, kmax = 0;
+};
+thread_local AxialHint g_hint;
+}  // namespace
+
+void set_axial_gauge_hint(const void *G_d, const void *E1_d, int dir, int sign, int kmax) {
+  g_hint.G = G_d;
+  g_hint.E1 = E1_d;
+  g_hint.dir = dir;
+  g_hint.sign = sign;
+  g_hint.kmax = kmax;
+}
+
+size_t axial_gauge_bytes(const MugiqHipSpinorField &ev, int dir, const int *kvals, int nK, int partitioned) {
+  if (!mfma_tile_applicable(ev, dir, kvals, nK, partitioned)) return 0;
+  return (size_t)9 * (ev.X[dir] + nK) * (size_t)(2 * ev.volumeCB / ev.X[dir]) * sizeof(Cplx<double>);
+}
+
+int build_axial_gauge(void *G_d, const MugiqHipSpinorField &ev, const void *const *E_d, int kmax, int dir, int sign, hipStream_t stream) {
+  AxialArgs g;
+  g.G = static_cast<Cplx<double> *>(G_d);
+  for (int l = 0; l < 4; l++) g.E[l] = static_cast<const Cplx<double> *>(E_d[l < kmax ? l : 0]);
+  long long strideMu = 1;
+  for (int d = 0; d < dir; d++) strideMu *= ev.X[d];
+  g.kmax = kmax;
+  g.sign = sign;
+  g.J = ev.X[dir];
+  g.strideMu = dir == 0 ? 1 : (int)(strideMu / 2);
+  g.H = (int)(ev.volumeCB / ((long long)ev.X[dir] * g.strideMu));
+  g.numCols = 2 * ev.volumeCB / ev.X[dir];
+  g.volumeCB = ev.volumeCB;
+  g.rowMode = dir == 0;
+  g.X1 = ev.X[1];
+  g.X2 = ev.X[2];
+  hipLaunchKernelGGL(axial_gauge_kernel, dim3((g.numCols + 63) / 64), dim3(64), 0, stream, g);
+  MUGIQ_CHECK_HIP(hipGetLastError());
+  return MUGIQ_HIP_SUCCESS;
+}
+
 // ultra_d != NULL: also produce the ultra-local loop (k = 0) into ultra_d as one more slot; *carried says whether that
 // happened (only a launch over the whole lattice may: see csrc/fused_tile.hip)
 int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d, const int *kvals,
@@ -582,27 +624,15 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
   region &= 0xff;
   if (region != MUGIQ_HIP_REGION_ALL) ultra_d = nullptr;
   a.kmax = nK;  // (mfma_tile_applicable: the lengths are 1 .. nK)
-  // the axial gauge of this (direction, sign), rebuilt per call into the stream's workspace (one pass over W_1)
-  {
-    const size_t gBytes = (size_t)9 * (ev[0].X[dir] + a.kmax) * a.numCols * sizeof(Cplx<double>);
+  // the axial gauge of this (direction, sign): the caller's, if it has built one from these links; else rebuilt into the stream's
+  // workspace (one pass over W_1)
+  if (g_hint.G && g_hint.E1 == E_d[0] && g_hint.dir == dir && g_hint.sign == sign && g_hint.kmax == a.kmax) {
+    a.G = static_cast<const Cplx<double> *>(g_hint.G);
+  } else {
     void *gbuf = nullptr;
-    if ((st = stream_workspace(&gbuf, gBytes, stream))) return st;
-    AxialArgs g;
-    g.G = static_cast<Cplx<double> *>(gbuf);
-    for (int l = 0; l < 4; l++) g.E[l] = static_cast<const Cplx<double> *>(E_d[l < nK ? l : 0]);
-    g.kmax = a.kmax;
-    g.sign = sign;
-    g.J = ev[0].X[dir];
-    g.strideMu = a.strideMu;
-    g.H = a.H;
-    g.numCols = a.numCols;
-    g.volumeCB = a.volumeCB;
-    g.rowMode = dir == 0;
-    g.X1 = ev[0].X[1];
-    g.X2 = ev[0].X[2];
-    hipLaunchKernelGGL(axial_gauge_kernel, dim3((a.numCols + 63) / 64), dim3(64), 0, stream, g);
-    MUGIQ_CHECK_HIP(hipGetLastError());
-    a.G = g.G;
+    if ((st = stream_workspace(&gbuf, (size_t)9 * (ev[0].X[dir] + a.kmax) * a.numCols * sizeof(Cplx<double>), stream))) return st;
+    if ((st = build_axial_gauge(gbuf, ev[0], E_d, a.kmax, dir, sign, stream))) return st;
+    a.G = static_cast<const Cplx<double> *>(gbuf);
   }
   int ns = nK;
   for (int s = 0; s < kMT_MaxSlots; s++) {

@@ -37,6 +37,13 @@ int release_stream_scratch(hipStream_t stream);
 size_t eo_dft_x_lds_bytes(int precision, const int localL[4], int nPx, int *redOffsetElems);  // momproj.hip
 int eo_dft_x_time_chunk(int precision, const int localL[4], int nPx);                            // momproj.hip: 0 = the fused x step does not apply
 int fill_identity_links(const MugiqHipSpinorField *f, hipStream_t stream);  // displace.hip
+// csrc/fused_mfma.hip.  The axial gauge of a (direction, sign) is rebuilt by every launch of the matrix-pipe tile (one pass over
+// W_1, 0.2 ms) -- unless the caller, who launches the same entry several times (the driver: interior tiles, then the boundary tiles
+// block by block), has built it once and says so: axial_gauge_bytes = 0 where that tile does not apply; the hint is per host
+// thread, names the W_1 field it was built from, and is cleared with G_d = NULL.
+size_t axial_gauge_bytes(const MugiqHipSpinorField &ev, int dir, const int *kvals, int nK, int partitioned);
+int build_axial_gauge(void *G_d, const MugiqHipSpinorField &ev, const void *const *E_d, int kmax, int dir, int sign, hipStream_t stream);
+void set_axial_gauge_hint(const void *G_d, const void *E1_d, int dir, int sign, int kmax);
 }  // namespace mugiq
 #include <vector>
 namespace mugiq {

@@ -112,6 +112,9 @@ struct MugiqHipLoop_s {
     std::vector<hipEvent_t> evPackedBlk, evBlock;
     int nBlocks = 0, blockN = 0;
     bool posted = false;
+    void *axialGauge = nullptr;  // the axial gauge of the entry, built once for all its launches (csrc/fused_mfma.hip), or NULL
+    bool selfAlias = false;  // the neighbour is this rank itself (an axis of extent 1 under forced partitioning): the face layers are
+                             // packed straight into the ghost buffer, no send buffer and no message (MUGIQ_HIP_SELF_HALO_COPY=1: keep them)
     std::vector<MugiqHipSpinorField> E;  // path-link fields built ahead (their small face exchanges go first)
   };
   std::vector<HaloPost> halo;   // per displacement entry
@@ -384,6 +387,15 @@ static int pool_reserve(MugiqHipLoop *lp, size_t bytes) {
   return MUGIQ_HIP_SUCCESS;
 }
 
+// An axis of extent 1 that is partitioned all the same (MugiqHipComm.partitioned): this rank is its own forward and backward
+// neighbour, the "message" would be a device copy of what the pack kernel has just written.  Pack into the ghost buffer instead.
+static bool self_neighbour_alias(const MugiqHipLoop *lp, int dir) {
+  if (!lp->haveComm || lp->comm.grid[dir] != 1) return false;
+  if (const char *e = getenv("MUGIQ_HIP_SELF_HALO_COPY"))
+    if (atoi(e) != 0) return false;
+  return true;
+}
+
 static int reserve_plan_buffers(MugiqHipLoop *lp) {
   if (lp->calcType == MUGIQ_HIP_LOOP_CALC_TYPE_BASIC_KERNEL || lp->nDispEntries == 0) return MUGIQ_HIP_SUCCESS;
   std::vector<char> ahead;
@@ -397,7 +409,14 @@ static int reserve_plan_buffers(MugiqHipLoop *lp) {
     for (int k = 0; k <= lp->dispStop[id]; k++)
       if ((st = pool_reserve(lp, fieldB))) return st;  // E_0 .. E_stop, held until the entry has run
     if ((st = pool_reserve(lp, faceB)) || (st = pool_reserve(lp, faceB))) return st;
-    if ((st = pool_reserve(lp, halo_bytes(lp, id))) || (st = pool_reserve(lp, halo_bytes(lp, id)))) return st;
+    if ((st = pool_reserve(lp, halo_bytes(lp, id)))) return st;
+    if (!self_neighbour_alias(lp, lp->dispDir[id]) && (st = pool_reserve(lp, halo_bytes(lp, id)))) return st;
+    {  // the entry's axial gauge (csrc/fused_mfma.hip), where that tile takes the entry
+      std::vector<int> kv;
+      for (int k = lp->dispStart[id]; k <= lp->dispStop[id]; k++) kv.push_back(k);
+      const size_t gb = axial_gauge_bytes(lp->eVecs[0], lp->dispDir[id], kv.data(), (int)kv.size(), 1);
+      if (gb && (st = pool_reserve(lp, gb))) return st;
+    }
     anyAhead = true;
   }
   // the entry that runs before the halos are posted keeps its link fields out of the pool until the compute ends (see
@@ -434,8 +453,22 @@ static int prepare_halo(MugiqHipLoop *lp, int id) {
     MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&h.evHalo, hipEventDisableTiming));
   }
   if ((st = build_path_links(lp, id, h.E))) return st;  // compute stream: the entry's kernels read them there
-  if ((st = scratch_alloc(lp, &h.gsend, bytes, false))) return st;
+  {  // the entry is launched once for its interior tiles and once per halo block for its boundary tiles: one gauge for all of them
+    std::vector<int> kv;
+    for (int k = lp->dispStart[id]; k <= lp->dispStop[id]; k++) kv.push_back(k);
+    const size_t gb = axial_gauge_bytes(lp->eVecs[0], lp->dispDir[id], kv.data(), (int)kv.size(), 1);
+    h.axialGauge = nullptr;
+    if (gb) {
+      std::vector<const void *> lk;
+      for (int k = 1; k <= lp->dispStop[id]; k++) lk.push_back(h.E[k].data);
+      if ((st = scratch_alloc(lp, &h.axialGauge, gb, false))) return st;
+      if ((st = build_axial_gauge(h.axialGauge, lp->eVecs[0], lk.data(), lp->dispStop[id], lp->dispDir[id], lp->dispSign[id], lp->stream))) return st;
+    }
+  }
+  h.selfAlias = self_neighbour_alias(lp, lp->dispDir[id]);
   if ((st = scratch_alloc(lp, &h.grecv, bytes, false))) return st;
+  if (h.selfAlias) h.gsend = h.grecv;
+  else if ((st = scratch_alloc(lp, &h.gsend, bytes, false))) return st;
   // all of these outlive the entries processed in between: move them from the per-entry list to the held list
   for (void *q : lp->scratch) lp->held.push_back(q);
   lp->scratch.clear();
@@ -477,7 +510,7 @@ static int send_halo_block(MugiqHipLoop *lp, int b, bool grouped) {
   if (grouped && (st = lp->comm.group_begin(lp->comm.ctx))) return set_error(MUGIQ_HIP_ERROR_HIP, "group_begin callback failed with status %d", st);
   for (int id = 0; id < lp->nDispEntries && !st; id++) {
     MugiqHipLoop::HaloPost &h = lp->halo[id];
-    if (!h.posted || b >= h.nBlocks) continue;
+    if (!h.posted || b >= h.nBlocks || h.selfAlias) continue;
     const int n0 = b * h.blockN, nv = std::min(h.blockN, lp->nEv - n0);
     const size_t perVec = halo_bytes(lp, id) / (size_t)lp->nEv;
     const int high = (lp->dispSign[id] == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
@@ -523,6 +556,12 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0, int part_sel = 0) 
     // the halo of all eigenvectors was posted at the start of the compute: interior tiles, then (once it has landed) the
     // boundary tiles
     MugiqHipLoop::HaloPost &h = lp->halo[id];
+    struct HintScope {  // the entry's own axial gauge for the launches below (cleared on every way out)
+      HintScope(const MugiqHipLoop::HaloPost &h, const std::vector<const void *> &links, int dir, int sign, int kmax) {
+        if (h.axialGauge) set_axial_gauge_hint(h.axialGauge, links[0], dir, sign, kmax);
+      }
+      ~HintScope() { set_axial_gauge_hint(nullptr, nullptr, -1, -1, 0); }
+    } hintScope(h, links, dir, sign, stop);
     int ph;
     if (part_sel != 2) {
       ph = phase_begin(lp, MUGIQ_HIP_PHASE_ENTRY_INTERIOR, id, lp->stream);
@@ -557,8 +596,9 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0, int part_sel = 0) 
     perVec = (size_t)stop * 24 * (lp->volumeCB / lp->localL[dir]) * lp->cplxBytes();
     const size_t budget = (size_t)4 << 30;  // 4 GiB per direction buffer
     nb = (int)std::max<size_t>(1, std::min<size_t>((size_t)lp->nEv, budget / perVec));
-    if ((st = scratch_alloc(lp, &gsend, perVec * nb, false))) return st;
     if ((st = scratch_alloc(lp, &grecv, perVec * nb, false))) return st;
+    if (self_neighbour_alias(lp, dir)) gsend = grecv;  // packed straight into the ghost buffer, no message
+    else if ((st = scratch_alloc(lp, &gsend, perVec * nb, false))) return st;
   }
   if (part && (st = ensure_comm_stream(lp))) return st;
   for (int n0 = 0; n0 < lp->nEv; n0 += nb) {
@@ -585,8 +625,10 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0, int part_sel = 0) 
     MUGIQ_CHECK_HIP(hipEventRecord(lp->evPacked, lp->stream));
     MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, lp->evPacked, 0));
     int ph = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_TRANSFER, id, lp->commStream, (double)(perVec * nv));
-    st = lp->comm.sendrecv(lp->comm.ctx, gsend, grecv, perVec * nv, dir, high ? +1 : -1, lp->commStream);
-    if (st) return set_error(MUGIQ_HIP_ERROR_HIP, "halo sendrecv callback failed with status %d", st);
+    if (gsend != grecv) {
+      st = lp->comm.sendrecv(lp->comm.ctx, gsend, grecv, perVec * nv, dir, high ? +1 : -1, lp->commStream);
+      if (st) return set_error(MUGIQ_HIP_ERROR_HIP, "halo sendrecv callback failed with status %d", st);
+    }
     phase_end(lp, ph, lp->commStream);
     MUGIQ_CHECK_HIP(hipEventRecord(lp->evHalo, lp->commStream));
     ph = phase_begin(lp, MUGIQ_HIP_PHASE_ENTRY_INTERIOR, id, lp->stream);

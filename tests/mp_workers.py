@@ -205,6 +205,7 @@ def nccl_world1_worker(rank, world, port, loopback):
     from util import orc, momenta_p2_le, rel_err
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["MUGIQ_HIP_SELF_HALO_COPY"] = "1"      # the halo to self goes through the transport (default: packed in place)
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -307,8 +308,9 @@ def forced_full_size_worker(rank, world, port, X, nev, force, backend):
 
     ref_pos, ref_mom, _, ref_der = run(g_plain, None, hip.LOOP_CALC_TYPE_OPT_KERNEL, ENTRIES_CFG2, nev)
     scale, mscale = float(ref_pos.abs().max()), float(np.abs(ref_mom).max())
-    for ahead in ("1", "0"):
+    for ahead, copy in (("1", "0"), ("0", "0"), ("1", "1"), ("0", "1")):   # copy 0: face layers packed straight into the ghost buffer
         os.environ["MUGIQ_HIP_HALO_AHEAD"] = ahead
+        os.environ["MUGIQ_HIP_SELF_HALO_COPY"] = copy
         pos, mom, kinds, der = run(g_part, comm, hip.LOOP_CALC_TYPE_OPT_KERNEL, ENTRIES_CFG2, nev)
         assert der == ref_der
         assert {"halo_transfer", "entry_interior", "entry_boundary"} <= kinds, kinds
@@ -318,6 +320,7 @@ def forced_full_size_worker(rank, world, port, X, nev, force, backend):
         assert em < 1e-12, ("forced partition, momentum space", em)
         del pos
     os.environ.pop("MUGIQ_HIP_HALO_AHEAD", None)
+    os.environ.pop("MUGIQ_HIP_SELF_HALO_COPY", None)
     # a second compute on the SAME loop object (position space only): pooled halo buffers, per-block events and link fields are reused
     prm = hip.MugiqLoopParam(gauge=g_part, calcType=hip.LOOP_CALC_TYPE_OPT_KERNEL).set_displace_entry_string(ENTRIES_CFG2)
     loop = hip.Loop_Mugiq(prm, f, sg, comm)
@@ -345,6 +348,7 @@ def native_rccl_worker(rank, world, port):
     import torch
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
+    os.environ["MUGIQ_HIP_SELF_HALO_COPY"] = "1"      # the halo to self goes through the transport (default: packed in place)
     import mugiq_amd as hip
     from bench import make_evecs, make_gauge, momenta_p2_le
     X, nev = (8, 8, 8, 8), 4
