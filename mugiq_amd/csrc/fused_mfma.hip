@@ -168,6 +168,9 @@ __global__ __launch_bounds__(64) void axial_gauge_kernel(AxialArgs a) {
 }
 
 #define MUGIQ_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f64_4x4x4f64(a_, b_, c_, 0, 0, 0)
+#ifndef MUGIQ_MT_DEPTH
+#define MUGIQ_MT_DEPTH 2  // raw eigenvectors in flight ahead of the one being rotated (probe builds: 3)
+#endif
 #ifndef MUGIQ_MT_EXPERIMENT
 #define MUGIQ_MT_EXPERIMENT 0  // probe builds only (tools/probes/build_exp.sh): 1 no global loads in the steps, 2 + no barrier, 3 + no rotation / commit, 4 staging only (no products)
 #endif
@@ -177,13 +180,14 @@ __global__ __launch_bounds__(64) void axial_gauge_kernel(AxialArgs a) {
 // positions past the end of the row (sign +) or before its start (sign -) are the row's own first / last sites, staged a
 // second time with the continued gauge g(J + l) | g(-l).  LDS image: chunk (parity, component) = [row][X0/2 + 2] complex.
 template <int DIR, int SIGN, int NS, int TJ, int LN>
-__global__ __launch_bounds__(64 * kMT_Waves) void mfma_tile_displaced_contract_kernel(MTileArgs a) {
+__global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile_displaced_contract_kernel(MTileArgs a) {  // 4 waves per SIMD: <= 128 VGPRs
   constexpr bool kRow = DIR == 0;
+  constexpr int kWaves = kRow ? TJ : kMT_Waves;  // (row tile: the TJ slot of the template carries the waves per workgroup, 8 | 16)
   constexpr int kMT_TJ = TJ, kMT_Cols = LN;
   constexpr int kPPC = kRow ? 1 : 64 / LN;                          // positions per chunk (2 | 4)
   constexpr int kMT_Groups = kRow ? LN / 16 : TJ * LN / 4 / kMT_Waves;  // 4-site groups per wave
   constexpr int kGP = LN / 4;                                       // groups per position
-  constexpr int kSites = kMT_Groups * 64;
+  constexpr int kSites = kMT_Groups * 4 * kWaves;
   extern __shared__ __align__(16) unsigned char smem[];
   Cplx<double> *tileBase = reinterpret_cast<Cplx<double> *>(smem);  // 2 x [pair][12][68]
   const int t = threadIdx.x, lane = t & 63;
@@ -211,6 +215,7 @@ __global__ __launch_bounds__(64 * kMT_Waves) void mfma_tile_displaced_contract_k
   for (int c = 0; c < 9; c++) g[c] = Cplx<double>{0.0, 0.0};
   int wIdx = 0;
   const int compStride = kRow ? a.rowChunk : kMT_Chunk;  // distance of two components in the LDS image
+  constexpr int bufElems = kWaves == 8 ? kMT_BufElems / 2 : kMT_BufElems;  // one tile buffer (two 8-wave workgroups share a CU's LDS)
   bool commits = stages;
   // row tile: rows of X0/2 entries per parity, + 2 slots for the continued positions (element m <-> position 2 (m - off) + delta)
   const int EPR = a.X[0] >> 1, EPRX = EPR + 2, rOff = SIGN == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : 2;
@@ -297,6 +302,9 @@ __global__ __launch_bounds__(64 * kMT_Waves) void mfma_tile_displaced_contract_k
 
   typedef double vec2 __attribute__((ext_vector_type(2)));
   vec2 stageA[3], stageB[3];
+#if MUGIQ_MT_DEPTH == 3
+  vec2 stageC[3];
+#endif
 #define MUGIQ_MT_BODY(n_) static_cast<const Cplx<double> *>(as_constant(a.L)[n_])
 #define MUGIQ_MT_SIGMA(n_) as_constant(a.inv_sigma)[n_]
   // this thread's three colours of eigenvector n_ (unconditional for the staging waves: a known number of loads in flight)
@@ -346,14 +354,14 @@ __global__ __launch_bounds__(64 * kMT_Waves) void mfma_tile_displaced_contract_k
     const double sNow = sigPre;                                                                                        \
     const Cplx<double> *bodyNow = bodyPre;                                                                             \
     {                                                                                                                  \
-      const int nb_ = (n_) + 4 < a.nVec ? (n_) + 4 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1;      \
+      const int nb_ = (n_) + 2 + MUGIQ_MT_DEPTH < a.nVec ? (n_) + 2 + MUGIQ_MT_DEPTH : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1; \
       bodyPre = MUGIQ_MT_BODY(nb_);                                                                                    \
       sigPre = MUGIQ_MT_SIGMA(ns_);                                                                                    \
     }                                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    if (MUGIQ_MT_EXPERIMENT != 3 && (GUARD == 0 || (n_) + 1 < a.nVec)) MUGIQ_MT_COMMIT(stage, tileBase + (size_t)(((n_) + 1) & 1) * kMT_BufElems) \
-    if ((MUGIQ_MT_EXPERIMENT == 0 || MUGIQ_MT_EXPERIMENT == 4) && (GUARD == 0 || (n_) + 3 < a.nVec)) MUGIQ_MT_FETCH(bodyNow, (n_) + 3, stage) \
-    if (MUGIQ_MT_EXPERIMENT != 4) MUGIQ_MT_COMPUTE(tileBase + (size_t)((n_) & 1) * kMT_BufElems, sNow)                 \
+    if (MUGIQ_MT_EXPERIMENT != 3 && (GUARD == 0 || (n_) + 1 < a.nVec)) MUGIQ_MT_COMMIT(stage, tileBase + (size_t)(((n_) + 1) & 1) * bufElems) \
+    if ((MUGIQ_MT_EXPERIMENT == 0 || MUGIQ_MT_EXPERIMENT == 4) && (GUARD == 0 || (n_) + 1 + MUGIQ_MT_DEPTH < a.nVec)) MUGIQ_MT_FETCH(bodyNow, (n_) + 1 + MUGIQ_MT_DEPTH, stage) \
+    if (MUGIQ_MT_EXPERIMENT != 4) MUGIQ_MT_COMPUTE(tileBase + (size_t)((n_) & 1) * bufElems, sNow)                     \
     MUGIQ_MT_BARRIER()                                                                                                 \
   }
   // prologue: eigenvector 0 -> buffer 0; eigenvectors 1 and 2 in flight (clamped, unconditional)
@@ -363,18 +371,27 @@ __global__ __launch_bounds__(64 * kMT_Waves) void mfma_tile_displaced_contract_k
     MUGIQ_MT_COMMIT(stageB, tileBase)
     MUGIQ_MT_FETCH(MUGIQ_MT_BODY((1 < last ? 1 : last)), (1 < last ? 1 : last), stageA)
     MUGIQ_MT_FETCH(MUGIQ_MT_BODY((2 < last ? 2 : last)), (2 < last ? 2 : last), stageB)
+#if MUGIQ_MT_DEPTH == 3
+    MUGIQ_MT_FETCH(MUGIQ_MT_BODY((3 < last ? 3 : last)), (3 < last ? 3 : last), stageC)
+#endif
   }
-  const Cplx<double> *bodyPre = MUGIQ_MT_BODY(a.nVec > 3 ? 3 : a.nVec - 1);
+  const Cplx<double> *bodyPre = MUGIQ_MT_BODY(a.nVec > MUGIQ_MT_DEPTH + 1 ? MUGIQ_MT_DEPTH + 1 : a.nVec - 1);
   double sigPre = MUGIQ_MT_SIGMA(0);
   MUGIQ_MT_BARRIER()
   int n = 0;
-  for (; n + 4 < a.nVec; n += 2) {
+  for (; n + 2 * MUGIQ_MT_DEPTH < a.nVec; n += MUGIQ_MT_DEPTH) {
     MUGIQ_MT_STEP(n, stageA, 0)
     MUGIQ_MT_STEP(n + 1, stageB, 0)
+#if MUGIQ_MT_DEPTH == 3
+    MUGIQ_MT_STEP(n + 2, stageC, 0)
+#endif
   }
-  for (; n < a.nVec; n += 2) {
+  for (; n < a.nVec; n += MUGIQ_MT_DEPTH) {
     MUGIQ_MT_STEP(n, stageA, 1)
     if (n + 1 < a.nVec) MUGIQ_MT_STEP(n + 1, stageB, 1)
+#if MUGIQ_MT_DEPTH == 3
+    if (n + 2 < a.nVec) MUGIQ_MT_STEP(n + 2, stageC, 1)
+#endif
   }
 #undef MUGIQ_MT_STEP
 #undef MUGIQ_MT_COMPUTE
@@ -397,7 +414,7 @@ __global__ __launch_bounds__(64 * kMT_Waves) void mfma_tile_displaced_contract_k
       scratch[(hi * 4 + lo) * kSites + site] = Cplx<double>{aR[gi][s], aI[gi][s]};
     }
     MUGIQ_MT_BARRIER()
-    for (int item = t; item < 2 * kSites; item += 64 * kMT_Waves) {
+    for (int item = t; item < 2 * kSites; item += 64 * kWaves) {
       const int half = item / kSites, site = item - half * kSites;
       int pmine, xmine;
       if constexpr (kRow) {
@@ -440,17 +457,25 @@ static int mfma_tile_tj(int extent, int kmax) {
   return 0;
 }
 
-// mu = x: R whole rows per workgroup, R X0 / 2 = 64 G entries per parity ... i.e. R X0 = 128 | 192 sites (G = 2 | 3 groups per wave)
-static bool mfma_row_geometry(const MugiqHipSpinorField &ev, int *groups, int *rows) {
+// mu = x: R whole rows per workgroup of W waves, G = 2 | 3 groups of 4 sites per wave: R X0 = 16 G W sites.  One workgroup of 16
+// waves per CU where the rows allow, else two of 8 (MUGIQ_HIP_MFMA_ROW_WAVES = 8 | 16 fixes it).
+static bool mfma_row_geometry(const MugiqHipSpinorField &ev, int *groups, int *rows, int *waves) {
   const int epr = ev.X[0] / 2, nRows = ev.volumeCB / epr;
   if (epr % 4 != 0) return false;
-  for (int g : {3, 2}) {
-    if ((32 * g) % epr != 0) continue;
-    const int r = 32 * g / epr;
-    if (nRows % r != 0 || r * 8 * (epr + 2) > 64 * kMT_Waves) continue;
-    *groups = g;
-    *rows = r;
-    return true;
+  int want = 0;
+  if (const char *e = getenv("MUGIQ_HIP_MFMA_ROW_WAVES")) want = atoi(e);
+  for (int w : {16, 8}) {  // (measured equal at X0 = 48: 11.6 ms per entry and 100 eigenvectors either way)
+    if (want && w != want) continue;
+    for (int g : {3, 2}) {
+      if ((2 * g * w) % epr != 0) continue;
+      const int r = 2 * g * w / epr;
+      if (nRows % r != 0 || r * 8 * (epr + 2) > 64 * w) continue;
+      if (24 * ((r * (epr + 2) + 11) / 16 * 16 + 4) > (w == 8 ? kMT_BufElems / 2 : kMT_BufElems)) continue;  // the LDS image of a tile buffer
+      *groups = g;
+      *rows = r;
+      *waves = w;
+      return true;
+    }
   }
   return false;
 }
@@ -474,25 +499,30 @@ bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, const int *kva
   const int kmax = nK;
   if (kmax > kMT_MaxSlots - 1 || kmax > ev.X[dir]) return false;
   if (dir == 0) {  // whole x rows: no ghost handling
-    int g, r;
+    int g, r, w;
     if (const char *e = getenv("MUGIQ_HIP_MFMA_ROW"))
       if (atoi(e) == 0) return false;
-    return !partitioned && mfma_row_geometry(ev, &g, &r);
+    return !partitioned && mfma_row_geometry(ev, &g, &r, &w);
   }
   return mfma_tile_tj(ev.X[dir], kmax) != 0;
 }
 
-static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, int rowGroups, hipStream_t stream) {
+static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, int rowGroups, int rowWaves, hipStream_t stream) {
   const int ln = tj == 4 ? 32 : 16;
-  const size_t shmem = std::max((size_t)2 * kMT_BufElems * sizeof(Cplx<double>), (size_t)16 * (dir == 0 ? 64 * rowGroups : tj * ln) * sizeof(Cplx<double>));
+  const size_t bufElems = dir == 0 && rowWaves == 8 ? kMT_BufElems / 2 : kMT_BufElems;
+  const size_t shmem = std::max(2 * bufElems, (size_t)16 * (dir == 0 ? 4 * rowGroups * rowWaves : tj * ln)) * sizeof(Cplx<double>);
   const unsigned nblocks = dir == 0 ? (unsigned)(a.numCols / a.rowsPerTile) : (unsigned)(((a.numCols + ln - 1) / ln) * a.jtCount);
   a.blockOrder = 2;
   if (const char *e = getenv("MUGIQ_HIP_TILE_ORDER")) a.blockOrder = atoi(e) & 2;
   if (nblocks % 8 != 0 || dir == 0) a.blockOrder = 0;
-  const dim3 grid(nblocks), block(64 * kMT_Waves);
+  const dim3 grid(nblocks), block(64 * (dir == 0 ? rowWaves : kMT_Waves));
 #define MUGIQ_MT_ROW(S, N)                                                                                             \
   {                                                                                                                    \
-    if (rowGroups == 3) MUGIQ_MT_LAUNCH_(0, S, N, 0, 48) else MUGIQ_MT_LAUNCH_(0, S, N, 0, 32)                         \
+    if (rowWaves == 8) {                                                                                               \
+      if (rowGroups == 3) MUGIQ_MT_LAUNCH_(0, S, N, 8, 48) else MUGIQ_MT_LAUNCH_(0, S, N, 8, 32)                       \
+    } else {                                                                                                           \
+      if (rowGroups == 3) MUGIQ_MT_LAUNCH_(0, S, N, 16, 48) else MUGIQ_MT_LAUNCH_(0, S, N, 16, 32)                     \
+    }                                                                                                                  \
   }
 #define MUGIQ_MT_ROWCASE(S)                                                                                            \
   case (S):                                                                                                            \
@@ -607,12 +637,12 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
   a.strideMu = (int)strideMu;
   a.H = (int)(ev[0].volumeCB / (ev[0].X[dir] * strideMu));
   a.numCols = 2 * ev[0].volumeCB / ev[0].X[dir];
-  int tj = 0, rowGroups = 0;
+  int tj = 0, rowGroups = 0, rowWaves = 0;
   a.rowsPerTile = a.rowChunk = 0;
   if (dir == 0) {
-    MUGIQ_REQUIRE(mfma_row_geometry(ev[0], &rowGroups, &a.rowsPerTile), "mfma tile: no row geometry for X0 = %d (internal)", ev[0].X[0]);
+    MUGIQ_REQUIRE(mfma_row_geometry(ev[0], &rowGroups, &a.rowsPerTile, &rowWaves), "mfma tile: no row geometry for X0 = %d (internal)", ev[0].X[0]);
     a.rowChunk = (a.rowsPerTile * (ev[0].X[0] / 2 + 2) + 11) / 16 * 16 + 4;  // >= R (X0/2 + 2), and 4 mod 16 entries: 16 banks of phase per component
-    MUGIQ_REQUIRE(24 * a.rowChunk <= kMT_BufElems, "mfma tile: row image of %d entries per chunk does not fit (internal)", a.rowChunk);
+    MUGIQ_REQUIRE(24 * a.rowChunk <= (rowWaves == 8 ? kMT_BufElems / 2 : kMT_BufElems), "mfma tile: row image of %d entries per chunk does not fit (internal)", a.rowChunk);
     ultra_d = nullptr;  // (the row tile takes no fourth slot)
     tj = ev[0].X[0];    // one "tile" along mu
   } else {
@@ -661,7 +691,7 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
     }
   }
   if (a.jtCount > 0) {
-    st = launch_mfma_tile(a, dir, sign, ns, tj, rowGroups, stream);
+    st = launch_mfma_tile(a, dir, sign, ns, tj, rowGroups, rowWaves, stream);
     if (st) return st;
     if (withUltra && carried) *carried = 1;
   }
