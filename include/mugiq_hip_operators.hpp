@@ -201,7 +201,7 @@ public:
       : comm_(comm), stream_(stream) {
     checkField<Float, fieldOrder>(csf, "Displace");
     for (int d = 0; d < 4; d++) {
-      commDim_[d] = (comm && comm->grid[d] > 1) ? 1 : 0;
+      commDim_[d] = (comm && (comm->grid[d] > 1 || comm->partitioned[d])) ? 1 : 0;  // comm_dim_partitioned(d), forced included
       exRng[d] = 2 * commDim_[d];  // lib/displace.cpp:16
     }
     if (lp->gauge_ext) gaugeField = lp->gauge_ext;
@@ -314,7 +314,7 @@ template <typename Float, int fieldOrder> class Loop_Mugiq {
       int X[4], R[4];
       for (int d = 0; d < 4; d++) {
         X[d] = gp.X[d];
-        R[d] = 2 * ((comm && comm->grid[d] > 1) ? 1 : 0);  // exRng[i] = 2 * redundantComms-or-commDimPartitioned, lib/displace.cpp:16
+        R[d] = 2 * ((comm && (comm->grid[d] > 1 || comm->partitioned[d])) ? 1 : 0);  // exRng[i] = 2 * redundantComms-or-commDimPartitioned, lib/displace.cpp:16
       }
       check(mugiq_hip_alloc_extended_gauge(&ownGauge_, X, R, precisionOf<Float>()));
       const void *links[4] = {lp->gauge[0], lp->gauge[1], lp->gauge[2], lp->gauge[3]};

@@ -7,6 +7,9 @@
 //   --dim x y z t  --nev N  --loop-ft-sign plus|minus  --loop-calc-type blas|opt|basic  --loop-do-momproj yes|no
 //   --loop-do-nonlocal yes|no  --displace-entry-string "+z:1,8;-x:3"  --momenta-filename FILE
 //   --loop-write-mom-space yes|no  --loop-mom-space-filename FILE  --check (compare with the C oracle, exit code)
+//   --partition MASK   QUDA's test flag (bit d = comm_dim_partitioned_set(d)): run the partitioned code path on those axes with
+//                      this one process as its own neighbour, through the library's own RCCL transport (mugiq_hip_rccl_comm_create:
+//                      gauge borders and eigenvector halos as ncclSend / ncclRecv) -- a C++ host needs neither MPI nor Python for it
 #include <hip/hip_runtime.h>
 
 #include <complex>
@@ -44,6 +47,7 @@ int main(int argc, char **argv) {
   int X[4] = {8, 8, 8, 8};
   int nev = 4;
   bool check = false;
+  int partitionMask = 0;
   std::string momFile;
   MugiqLoopParam lp;
   for (int i = 1; i < argc; i++) {
@@ -60,6 +64,7 @@ int main(int argc, char **argv) {
     else if (a == "--loop-write-mom-space") lp.writeMomSpaceHDF5 = yes(next()) ? MUGIQ_BOOL_TRUE : MUGIQ_BOOL_FALSE;
     else if (a == "--loop-mom-space-filename") lp.fname_mom_h5 = next();
     else if (a == "--check") check = true;
+    else if (a == "--partition") partitionMask = atoi(next().c_str());
     else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
   }
   if (lp.doMomProj == MUGIQ_BOOL_TRUE) {  // tests/loop.cpp:724-740: one "px py pz" triple per line
@@ -111,8 +116,19 @@ int main(int argc, char **argv) {
   lp.gauge_param = &gp;
 
   int rc = 0;
+  MugiqHipRcclComm *rccl = nullptr;
+  MugiqHipComm comm;
+  if (partitionMask) {
+    char id[128];
+    const int grid[4] = {1, 1, 1, 1}, part[4] = {partitionMask & 1, (partitionMask >> 1) & 1, (partitionMask >> 2) & 1, (partitionMask >> 3) & 1};
+    if (mugiq_hip_rccl_get_unique_id(id) || mugiq_hip_rccl_comm_create(&rccl, id, 0, 1, grid, part) || mugiq_hip_rccl_comm_fill(rccl, &comm)) {
+      fprintf(stderr, "RCCL transport: %s\n", mugiq_hip_last_error());
+      return 2;
+    }
+    printf("partitioned axes (x y z t): %d %d %d %d through the library's RCCL transport\n", part[0], part[1], part[2], part[3]);
+  }
   try {
-    Loop_Mugiq<double, FLOAT2_FIELD_ORDER> loop(&lp, eVecs, sigma);
+    Loop_Mugiq<double, FLOAT2_FIELD_ORDER> loop(&lp, eVecs, sigma, partitionMask ? &comm : nullptr);
     loop.computeCoarseLoop();
     if (lp.writeMomSpaceHDF5 == MUGIQ_BOOL_TRUE) loop.writeLoopsHDF5();
     MugiqHipLoopInfo info = loop.info();
@@ -191,6 +207,7 @@ int main(int argc, char **argv) {
     rc = 1;
   }
   for (void *p : dptr) (void)hipFree(p);
+  mugiq_hip_rccl_comm_destroy(rccl);
   printf(rc == 0 ? "LOOP TEST PASSED\n" : "LOOP TEST FAILED\n");
   return rc;
 }
