@@ -168,12 +168,6 @@ __global__ __launch_bounds__(64) void axial_gauge_kernel(AxialArgs a) {
 }
 
 #define MUGIQ_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f64_4x4x4f64(a_, b_, c_, 0, 0, 0)
-#ifndef MUGIQ_MT_DEPTH
-#define MUGIQ_MT_DEPTH 2  // raw eigenvectors in flight ahead of the one being rotated (probe builds: 3)
-#endif
-#ifndef MUGIQ_MT_EXPERIMENT
-#define MUGIQ_MT_EXPERIMENT 0  // probe builds only (tools/probes/build_exp.sh): 1 no global loads in the steps, 2 + no barrier, 3 + no rotation / commit, 4 staging only (no products)
-#endif
 
 // mu = x (DIR == 0, "row tile"): the lines run along the coalescing direction, so a workgroup owns R whole x rows (both
 // parities; R X0 = 128 | 192 sites, TJ = 0 and LN = 16 * groups per wave in the template) and there is no halo at all: the
@@ -302,9 +296,6 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
 
   typedef double vec2 __attribute__((ext_vector_type(2)));
   vec2 stageA[3], stageB[3];
-#if MUGIQ_MT_DEPTH == 3
-  vec2 stageC[3];
-#endif
 #define MUGIQ_MT_BODY(n_) static_cast<const Cplx<double> *>(as_constant(a.L)[n_])
 #define MUGIQ_MT_SIGMA(n_) as_constant(a.inv_sigma)[n_]
   // this thread's three colours of eigenvector n_ (unconditional for the staging waves: a known number of loads in flight)
@@ -326,7 +317,7 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
 #define MUGIQ_MT_BARRIER()                              \
   {                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    if (MUGIQ_MT_EXPERIMENT != 2 && MUGIQ_MT_EXPERIMENT != 3) __builtin_amdgcn_s_barrier(); \
+    __builtin_amdgcn_s_barrier();                       \
     asm volatile("" ::: "memory");                      \
   }
   // the products of one eigenvector (scaled by s_) on the tile buffer tile_
@@ -354,14 +345,14 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
     const double sNow = sigPre;                                                                                        \
     const Cplx<double> *bodyNow = bodyPre;                                                                             \
     {                                                                                                                  \
-      const int nb_ = (n_) + 2 + MUGIQ_MT_DEPTH < a.nVec ? (n_) + 2 + MUGIQ_MT_DEPTH : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1; \
+      const int nb_ = (n_) + 4 < a.nVec ? (n_) + 4 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1;      \
       bodyPre = MUGIQ_MT_BODY(nb_);                                                                                    \
       sigPre = MUGIQ_MT_SIGMA(ns_);                                                                                    \
     }                                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    if (MUGIQ_MT_EXPERIMENT != 3 && (GUARD == 0 || (n_) + 1 < a.nVec)) MUGIQ_MT_COMMIT(stage, tileBase + (size_t)(((n_) + 1) & 1) * bufElems) \
-    if ((MUGIQ_MT_EXPERIMENT == 0 || MUGIQ_MT_EXPERIMENT == 4) && (GUARD == 0 || (n_) + 1 + MUGIQ_MT_DEPTH < a.nVec)) MUGIQ_MT_FETCH(bodyNow, (n_) + 1 + MUGIQ_MT_DEPTH, stage) \
-    if (MUGIQ_MT_EXPERIMENT != 4) MUGIQ_MT_COMPUTE(tileBase + (size_t)((n_) & 1) * bufElems, sNow)                     \
+    if (GUARD == 0 || (n_) + 1 < a.nVec) MUGIQ_MT_COMMIT(stage, tileBase + (size_t)(((n_) + 1) & 1) * bufElems)        \
+    if (GUARD == 0 || (n_) + 3 < a.nVec) MUGIQ_MT_FETCH(bodyNow, (n_) + 3, stage)                                      \
+    MUGIQ_MT_COMPUTE(tileBase + (size_t)((n_) & 1) * bufElems, sNow)                                                   \
     MUGIQ_MT_BARRIER()                                                                                                 \
   }
   // prologue: eigenvector 0 -> buffer 0; eigenvectors 1 and 2 in flight (clamped, unconditional)
@@ -371,27 +362,18 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
     MUGIQ_MT_COMMIT(stageB, tileBase)
     MUGIQ_MT_FETCH(MUGIQ_MT_BODY((1 < last ? 1 : last)), (1 < last ? 1 : last), stageA)
     MUGIQ_MT_FETCH(MUGIQ_MT_BODY((2 < last ? 2 : last)), (2 < last ? 2 : last), stageB)
-#if MUGIQ_MT_DEPTH == 3
-    MUGIQ_MT_FETCH(MUGIQ_MT_BODY((3 < last ? 3 : last)), (3 < last ? 3 : last), stageC)
-#endif
   }
-  const Cplx<double> *bodyPre = MUGIQ_MT_BODY(a.nVec > MUGIQ_MT_DEPTH + 1 ? MUGIQ_MT_DEPTH + 1 : a.nVec - 1);
+  const Cplx<double> *bodyPre = MUGIQ_MT_BODY(a.nVec > 3 ? 3 : a.nVec - 1);
   double sigPre = MUGIQ_MT_SIGMA(0);
   MUGIQ_MT_BARRIER()
   int n = 0;
-  for (; n + 2 * MUGIQ_MT_DEPTH < a.nVec; n += MUGIQ_MT_DEPTH) {
+  for (; n + 4 < a.nVec; n += 2) {
     MUGIQ_MT_STEP(n, stageA, 0)
     MUGIQ_MT_STEP(n + 1, stageB, 0)
-#if MUGIQ_MT_DEPTH == 3
-    MUGIQ_MT_STEP(n + 2, stageC, 0)
-#endif
   }
-  for (; n < a.nVec; n += MUGIQ_MT_DEPTH) {
+  for (; n < a.nVec; n += 2) {
     MUGIQ_MT_STEP(n, stageA, 1)
     if (n + 1 < a.nVec) MUGIQ_MT_STEP(n + 1, stageB, 1)
-#if MUGIQ_MT_DEPTH == 3
-    if (n + 2 < a.nVec) MUGIQ_MT_STEP(n + 2, stageC, 1)
-#endif
   }
 #undef MUGIQ_MT_STEP
 #undef MUGIQ_MT_COMPUTE
