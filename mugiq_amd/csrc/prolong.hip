@@ -984,18 +984,24 @@ struct ProlongMfmaArgs {
 // packed[((site * 2 + chi) * NV + j) * nVec8 + n] = phi_n(site; chi, j), site = parity * volumeCBc + x_cb_c, zero for
 // nVec <= n < nVec8.  A fragment load of a wave (16 rows = 8 eigenvectors x re | im, 4 values of j) is then four 128-byte
 // lines; from the fields themselves it would be 32 scattered 16-byte pieces of 32 different lines.
+// A workgroup transposes a tile of 16 coarse sites x 16 eigenvectors of one (parity, chi, j) through LDS: the reads run along
+// x_cb inside each eigenvector's field (256-byte runs), the writes along n inside the packed copy (256-byte runs).  (With
+// one thread per packed element and n fastest, every 16-byte read came from a different field: 4.0 x the bytes fetched.)
 __global__ __launch_bounds__(256) void coarse_pack_kernel(ProlongMfmaArgs a, int NV) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)2 * a.volumeCBc * 2 * NV * a.nVec8;
-  if (idx >= total) return;
-  const int n = (int)(idx % a.nVec8);
-  const int64_t r = idx / a.nVec8;
-  const int cj = (int)(r % (2 * NV));
-  const int64_t siteEo = r / (2 * NV);
-  const int cpar = (int)(siteEo / a.volumeCBc), xc = (int)(siteEo - (int64_t)cpar * a.volumeCBc);
-  Cplx<double> v{0.0, 0.0};
-  if (n < a.nVec) v = static_cast<const Cplx<double> *>(a.table[n])[(int64_t)cpar * a.Cpo + (int64_t)cj * a.Cstride + xc];
-  const_cast<Cplx<double> *>(a.packed)[idx] = v;
+  __shared__ Cplx<double> tile[16][17];
+  const int nT = (a.nVec8 + 15) / 16;  // tiles of 16 eigenvectors (nVec8 is a multiple of 8: the last tile may be half empty)
+  const int xt = blockIdx.x, cj = blockIdx.y, nt = blockIdx.z % nT, cpar = blockIdx.z / nT;
+  const int hi = threadIdx.x >> 4, lo = threadIdx.x & 15;
+  {
+    const int n = nt * 16 + hi, xc = xt * 16 + lo;
+    Cplx<double> v{0.0, 0.0};
+    if (n < a.nVec && xc < a.volumeCBc) v = static_cast<const Cplx<double> *>(a.table[n])[(int64_t)cpar * a.Cpo + (int64_t)cj * a.Cstride + xc];
+    tile[hi][lo] = v;
+  }
+  __syncthreads();
+  const int xc = xt * 16 + hi, n = nt * 16 + lo;
+  if (xc < a.volumeCBc && n < a.nVec8)
+    const_cast<Cplx<double> *>(a.packed)[(((int64_t)cpar * a.volumeCBc + xc) * (2 * NV) + cj) * a.nVec8 + n] = tile[lo][hi];
 }
 
 template <int NV> __global__ __launch_bounds__(64 * kPmWaves) void prolong_mfma_kernel(ProlongMfmaArgs a) {
@@ -1179,8 +1185,8 @@ static int prolong_mfma_plan(const MugiqHipTransfer *T, const MugiqHipCoarseFiel
   const size_t packBytes = sizeof(Cplx<double>) * (size_t)volc * 2 * NV * (size_t)a.nVec8;
   if ((st = stream_workspace(&ws, packBytes, stream))) return st;
   a.packed = static_cast<const Cplx<double> *>(ws);
-  const int64_t total = (int64_t)volc * 2 * NV * a.nVec8;
-  hipLaunchKernelGGL(coarse_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, NV);
+  const int nVec16 = (a.nVec8 + 15) / 16;  // (tiles of 16 eigenvectors; the last one may be half empty)
+  hipLaunchKernelGGL(coarse_pack_kernel, dim3((unsigned)((a.volumeCBc + 15) / 16), (unsigned)(2 * NV), (unsigned)(2 * nVec16)), dim3(256), 0, stream, a, NV);
   MUGIQ_CHECK_HIP(hipGetLastError());
   // passes: a workgroup keeps 4 * kPmPairs blocks of eight eigenvectors per chirality resident; more eigenvectors than that
   // are split evenly (V is staged once per pass: 12 n_vec 16 B per site against 192 B per site and eigenvector written)
