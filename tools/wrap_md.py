@@ -42,4 +42,4 @@ for l in lines:
     buf.append(l)
 flush()
 open(p, "w", encoding="utf-8").write("\n".join(res))
-print(max(len(x) for x in res))
+print(max(len(x) for x in "\n".join(res).split("\n")))
