@@ -770,6 +770,8 @@ def compact_line(out, detail_path):
     nt = (out.get("also_measured") or {}).get("native_rccl_transport")
     if isinstance(nt, dict) and "seconds" in nt:
         line["native_rccl"] = {k: nt[k] for k in ("seconds", "speedup", "max_rel_diff_vs_1gpu") if nt.get(k) is not None}
+        if isinstance(nt.get("multipath"), dict):
+            line["native_rccl"].update({"multipath_" + k: nt["multipath"][k] for k in ("seconds", "speedup", "max_rel_diff_vs_1gpu") if nt["multipath"].get(k) is not None})
     also = out.get("also_measured")
     if also:
         line["legs"] = {k: (_leg_summary(v) if isinstance(v, dict) else str(v)[:160]) for k, v in also.items()}
@@ -813,16 +815,27 @@ def extra_native(hip, device, a, world, rank, backend):
     if not _STRONG_REF:
         return {"skipped": "no strong-scaling reference in this run"}
     r = _STRONG_REF
-    comm = hip.RcclComm(r["grid"], device=device)
-    out = displaced_job(hip, device, r["X"], r["nev"], 8, comm, world, reps=1, backend=backend, hashed=True)
-    mom = out.pop("_mom")
-    comm.close()
-    out["workload"] = "the strong-scaling job (48x48x48x96 global, N_ev=%d) on mugiq_hip_rccl_comm_create's transport" % r["nev"]
+    out = None
+    for multipath in (False, True):          # one message per neighbour, then every message over 1 + 6 xGMI paths (two hops through the other GPUs)
+        if multipath and world <= 2:
+            break
+        comm = hip.RcclComm(r["grid"], device=device, multipath=multipath)
+        rec = displaced_job(hip, device, r["X"], r["nev"], 8, comm, world, reps=1, backend=backend, hashed=True)
+        mom = rec.pop("_mom")
+        comm.close()
+        rec["seconds_1gpu"] = r["seconds"]
+        rec["speedup"] = r["seconds"] / rec["seconds"]
+        rec["max_rel_diff_vs_1gpu"] = max_rel_diff(mom, r["mom"])
+        rec["parity_ok"] = bool(rec["max_rel_diff_vs_1gpu"] < PARITY_TOL)
+        if not multipath:
+            out = rec
+        else:
+            out["multipath"] = {k: rec[k] for k in ("seconds", "speedup", "max_rel_diff_vs_1gpu", "parity_ok", "phase_ms")}
+            out["multipath"]["halo"] = rec.get("halo")
+            out["parity_ok"] = bool(out["parity_ok"] and rec["parity_ok"])
+    out["workload"] = "the strong-scaling job (48x48x48x96 global, N_ev=%d) on mugiq_hip_rccl_comm_create's transport; `multipath`: the same with " \
+                      "every halo message cut over 1 + 6 xGMI paths" % r["nev"]
     out["grid"], out["local_lattice"], out["n_ev"] = list(r["grid"]), list(r["X"]), r["nev"]
-    out["seconds_1gpu"] = r["seconds"]
-    out["speedup"] = r["seconds"] / out["seconds"]
-    out["max_rel_diff_vs_1gpu"] = max_rel_diff(mom, r["mom"])
-    out["parity_ok"] = bool(out["max_rel_diff_vs_1gpu"] < PARITY_TOL)
     return out
 
 

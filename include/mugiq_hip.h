@@ -426,6 +426,18 @@ int mugiq_hip_rccl_comm_create(MugiqHipRcclComm **out, const void *id128, int ra
 int mugiq_hip_rccl_comm_from_nccl(MugiqHipRcclComm **out, void *ncclComm_world, const int grid[4], const int partitioned[4]);
 int mugiq_hip_rccl_comm_fill(MugiqHipRcclComm *c, MugiqHipComm *out);
 int mugiq_hip_rccl_comm_destroy(MugiqHipRcclComm *c);
+/* Multi-path halos (off by default; needs more than two ranks).  A halo message goes to ONE neighbour, i.e. over one of a GPU's
+ * seven xGMI links, while the links to the GPUs that are no neighbour on that axis idle: with this on, every sendrecv of a transfer
+ * group is cut into 1 + R parts (R <= 6 ranks that are neither the origin nor the destination); part 0 travels directly, the others
+ * through one relay each, first hops in one ncclGroup, second hops in the next, through a bounce buffer the communicator owns (about
+ * the size of the group's messages).  Every rank must switch it the same way.  The schedule (a pure function of rank, grid, axis,
+ * direction and size) is exposed for inspection: mugiq_hip_rccl_relay_plan lists what `rank` posts for one message -- phase 1 | 2,
+ * kind 0 send from the send buffer, 1 receive into the receive buffer, 2 receive into the bounce area, 3 send from the bounce area,
+ * peer, byte offset and length -- and returns the number of operations (tests/test_rccl_relay_plan_cpu.py delivers every byte with
+ * it on a simulated network).  Never run on hardware (one-GPU boxes). */
+int mugiq_hip_rccl_comm_set_multipath(MugiqHipRcclComm *c, int on);
+int mugiq_hip_rccl_relay_plan(int rank, const int grid[4], int dim, int dir, size_t bytes, int max_ops, int *phase, int *kind, int *peer,
+                              size_t *offset, size_t *len, size_t *bounce_bytes);
 
 /* exchangeGhostVec(ColorSpinorField *x), lib/contract_wrappers.cu:166-169 (x->exchangeGhost(QUDA_INVALID_PARITY, nFace = 1, 0)):
  * fill the depth-1 ghost zones v->ghost[d][0 | 1] of every partitioned dimension (comm->grid[d] > 1 or comm->partitioned[d]), both directions,

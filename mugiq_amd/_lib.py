@@ -92,6 +92,9 @@ SIGNATURES = {
     "mugiq_hip_rccl_comm_from_nccl": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _VP, _I4, _I4]),
     "mugiq_hip_rccl_comm_fill": (ctypes.c_int, [_VP, _VP]),
     "mugiq_hip_rccl_comm_destroy": (ctypes.c_int, [_VP]),
+    "mugiq_hip_rccl_comm_set_multipath": (ctypes.c_int, [_VP, ctypes.c_int]),
+    "mugiq_hip_rccl_relay_plan": (ctypes.c_int, [ctypes.c_int, _I4, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, _I4, _I4, _I4,
+                                                ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "mugiq_hip_alloc_spinor_like": (ctypes.c_int, [_SP, _SP, ctypes.c_int, _I4]),
     "mugiq_hip_free_spinor": (ctypes.c_int, [_SP]),
     "mugiq_hip_copy_spinor": (ctypes.c_int, [_SP, _SP, _VP]),

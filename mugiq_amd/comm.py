@@ -303,7 +303,8 @@ class RcclComm:
     from mugiq_hip_rccl_comm_create.  One process: nothing else is needed.  Several: torch.distributed (any backend) must be
     initialised -- it only carries the 128-byte ncclUniqueId from rank 0 to the others; every rank must construct this (collective)."""
 
-    def __init__(self, grid, device=None, force_partitioned=(0, 0, 0, 0)):
+    def __init__(self, grid, device=None, force_partitioned=(0, 0, 0, 0), multipath=False):
+        """multipath: halo messages over several xGMI paths at once (mugiq_hip_rccl_comm_set_multipath; more than two ranks)"""
         lib = _lib.load()
         self.grid = tuple(int(g) for g in grid)
         self.force_partitioned = tuple(1 if f else 0 for f in force_partitioned)
@@ -329,6 +330,9 @@ class RcclComm:
         _lib.check(lib.mugiq_hip_rccl_comm_fill(self._h, ctypes.byref(self._c)))
         self.coord = tuple(self._c.coord)
         self.backend = "rccl-native"
+        self.multipath = bool(multipath) and self.size > 2
+        if multipath:
+            _lib.check(lib.mugiq_hip_rccl_comm_set_multipath(self._h, 1))
 
     def comm_dim_partitioned(self, d):
         return 1 if (self.grid[d] > 1 or self.force_partitioned[d]) else 0

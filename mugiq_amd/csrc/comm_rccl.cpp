@@ -17,6 +17,7 @@
 // library itself keeps no link dependency on it.  Rank <-> coordinate map: QUDA's default, t fastest (as mugiq_amd/comm.py).
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -99,6 +100,18 @@ struct MugiqHipRcclComm_s {
   int grid[4] = {1, 1, 1, 1}, coord[4] = {0, 0, 0, 0}, partitioned[4] = {0, 0, 0, 0};
   bool isTimeProcess = true;
   int groupDepth = 0;
+  // multi-path halos (see relay_plan): the messages of a transfer group are collected and issued at group_end in two phases
+  bool multipath = false;
+  struct Msg {
+    const void *send;
+    void *recv;
+    size_t bytes;
+    int dim, dir;
+    hipStream_t stream;
+  };
+  std::vector<Msg> pending;
+  void *bounce = nullptr;
+  size_t bounceBytes = 0;
   hipStream_t hostStream = nullptr;  // the reductions of host payloads run here
   void *stage[2] = {nullptr, nullptr};
   size_t stageBytes[2] = {0, 0};
@@ -124,15 +137,154 @@ struct MugiqHipRcclComm_s {
 
 namespace {
 
+// ---- multi-path halos ------------------------------------------------------------------------------------------------------
+// A halo message goes to ONE neighbour, i.e. over ONE of a GPU's seven xGMI links, while the links to the GPUs that are no
+// neighbour on that axis idle.  With `multipath` a message of B bytes is cut into 1 + R parts (R = the ranks that are neither its
+// origin nor its destination, at most 6): part 0 travels directly, part p goes to relay p in a first phase and from there to
+// the destination in a second one; every rank is origin, destination and relay at once, the schedule is a pure function of
+// (rank, grid, dim, dir, B), and each phase is one ncclGroup in which every send has its receive on the peer.  Between a pair of
+// ranks a message causes at most one transfer per phase (a rank is either the destination or a relay of an origin, never both),
+// so the order in which NCCL pairs sends and receives of a peer is the order of the messages, the same on every rank.
+enum { kOpSendUser = 0, kOpRecvUser = 1, kOpRecvBounce = 2, kOpSendBounce = 3 };
+struct RelayOp {
+  int phase, kind, peer;
+  size_t offset, len;  // offset into the user's send / receive buffer, or into this message's bounce area
+};
+int rank_of(const int grid[4], const int c[4]) { return ((c[0] * grid[1] + c[1]) * grid[2] + c[2]) * grid[3] + c[3]; }
+void coords_of(const int grid[4], int r, int c[4]) {
+  c[3] = r % grid[3];
+  r /= grid[3];
+  c[2] = r % grid[2];
+  r /= grid[2];
+  c[1] = r % grid[1];
+  c[0] = r / grid[1];
+}
+int shifted(const int grid[4], int r, int dim, int dir) {
+  int c[4];
+  coords_of(grid, r, c);
+  c[dim] = (c[dim] + dir + grid[dim]) % grid[dim];
+  return rank_of(grid, c);
+}
+// the relays of origin o, in the order of their parts: every rank but o and its destination (at most kMaxRelays of them, the
+// ones closest after o in rank order, so that different origins spread over different relays)
+constexpr int kMaxRelays = 6;
+void relays_of(const int grid[4], int size, int o, int dim, int dir, std::vector<int> &out) {
+  out.clear();
+  const int f = shifted(grid, o, dim, dir);
+  for (int i = 1; i < size && (int)out.size() < kMaxRelays; i++) {
+    const int r = (o + i) % size;
+    if (r != o && r != f) out.push_back(r);
+  }
+}
+size_t relay_chunk(size_t bytes, int nRelays) {
+  const size_t c = (bytes + (size_t)nRelays) / ((size_t)nRelays + 1);
+  return (c + 255) / 256 * 256;
+}
+void relay_plan(int rank, const int grid[4], int dim, int dir, size_t bytes, std::vector<RelayOp> &ops, size_t *bounceBytes) {
+  ops.clear();
+  const int size = grid[0] * grid[1] * grid[2] * grid[3];
+  const int dst = shifted(grid, rank, dim, dir), src = shifted(grid, rank, dim, -dir);
+  std::vector<int> rel;
+  relays_of(grid, size, rank, dim, dir, rel);
+  const int R = dst == rank ? 0 : (int)rel.size();  // (a self-neighbour gets everything "directly")
+  const size_t chunk = relay_chunk(bytes, R);
+  auto part = [&](int p, size_t &off, size_t &len) {
+    off = std::min(bytes, (size_t)p * chunk);
+    len = std::min(bytes, (size_t)(p + 1) * chunk) - off;
+  };
+  size_t off, len;
+  part(0, off, len);
+  ops.push_back({1, kOpSendUser, dst, off, len});
+  ops.push_back({1, kOpRecvUser, src, off, len});
+  for (int p = 1; p <= R; p++) {  // my own parts to their relays
+    part(p, off, len);
+    if (len) ops.push_back({1, kOpSendUser, rel[p - 1], off, len});
+  }
+  size_t slot = 0;
+  if (R > 0)
+    for (int o = 0; o < size; o++) {  // the parts I relay: origin o, I am entry q - 1 of its list
+      if (o == rank) continue;
+      std::vector<int> ro;
+      relays_of(grid, size, o, dim, dir, ro);
+      for (int q = 1; q <= (int)ro.size(); q++)
+        if (ro[q - 1] == rank) {
+          part(q, off, len);
+          if (len) {
+            ops.push_back({1, kOpRecvBounce, o, slot * chunk, len});
+            ops.push_back({2, kOpSendBounce, shifted(grid, o, dim, dir), slot * chunk, len});
+          }
+          slot++;
+        }
+    }
+  if (R > 0) {  // the relayed parts of the message meant for me (origin: src)
+    std::vector<int> rs;
+    relays_of(grid, size, src, dim, dir, rs);
+    for (int p = 1; p <= (int)rs.size(); p++) {
+      part(p, off, len);
+      if (len) ops.push_back({2, kOpRecvUser, rs[p - 1], off, len});
+    }
+  }
+  if (bounceBytes) *bounceBytes = slot * chunk;
+}
+
+// the collected messages of a group over all paths: phase 1 (direct parts, first hops), then phase 2 (second hops), one ncclGroup each
+int flush_multipath(MugiqHipRcclComm *c) {
+  std::vector<std::vector<RelayOp>> plans(c->pending.size());
+  std::vector<size_t> bounceOff(c->pending.size());
+  size_t total = 0;
+  for (size_t i = 0; i < c->pending.size(); i++) {
+    size_t b = 0;
+    relay_plan(c->rank, c->grid, c->pending[i].dim, c->pending[i].dir, c->pending[i].bytes, plans[i], &b);
+    bounceOff[i] = total;
+    total += b;
+  }
+  if (total > c->bounceBytes) {
+    if (c->bounce) {  // (messages of an earlier group may still be reading it on their stream)
+      for (auto &m : c->pending) MUGIQ_CHECK_HIP(hipStreamSynchronize(m.stream));
+      (void)hipFree(c->bounce);
+    }
+    c->bounce = nullptr;
+    c->bounceBytes = 0;
+    MUGIQ_CHECK_HIP(hipMalloc(&c->bounce, total));
+    c->bounceBytes = total;
+  }
+  for (int phase = 1; phase <= 2; phase++) {
+    MUGIQ_CHECK_NCCL(g_api.GroupStart());
+    int r = kNcclSuccess;
+    for (size_t i = 0; i < c->pending.size() && r == kNcclSuccess; i++) {
+      const auto &m = c->pending[i];
+      char *bnc = static_cast<char *>(c->bounce) + bounceOff[i];
+      for (const RelayOp &op : plans[i]) {
+        if (op.phase != phase || r != kNcclSuccess) continue;
+        if (op.kind == kOpSendUser) r = g_api.Send(static_cast<const char *>(m.send) + op.offset, op.len, kNcclInt8, op.peer, c->world, m.stream);
+        else if (op.kind == kOpRecvUser) r = g_api.Recv(static_cast<char *>(m.recv) + op.offset, op.len, kNcclInt8, op.peer, c->world, m.stream);
+        else if (op.kind == kOpRecvBounce) r = g_api.Recv(bnc + op.offset, op.len, kNcclInt8, op.peer, c->world, m.stream);
+        else r = g_api.Send(bnc + op.offset, op.len, kNcclInt8, op.peer, c->world, m.stream);
+      }
+    }
+    const int r2 = g_api.GroupEnd();
+    if (r == kNcclSuccess) r = r2;
+    if (r != kNcclSuccess) {
+      c->pending.clear();
+      return mugiq::set_error(MUGIQ_HIP_ERROR_HIP, "mugiq_hip_rccl: multi-path halo, phase %d: %s", phase, g_api.GetErrorString(r));
+    }
+  }
+  c->pending.clear();
+  return MUGIQ_HIP_SUCCESS;
+}
+
 int cb_group_begin(void *ctx) {
   auto *c = static_cast<MugiqHipRcclComm *>(ctx);
-  if (c->groupDepth++ == 0) MUGIQ_CHECK_NCCL(g_api.GroupStart());
+  if (c->groupDepth++ == 0 && !c->multipath) MUGIQ_CHECK_NCCL(g_api.GroupStart());
   return MUGIQ_HIP_SUCCESS;
 }
 int cb_group_end(void *ctx, void * /*stream: the members of the group carry their own*/) {
   auto *c = static_cast<MugiqHipRcclComm *>(ctx);
   if (c->groupDepth <= 0) return mugiq::set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "mugiq_hip_rccl: group_end without group_begin");
-  if (--c->groupDepth == 0) MUGIQ_CHECK_NCCL(g_api.GroupEnd());
+  if (--c->groupDepth == 0) {
+    if (c->multipath) return flush_multipath(c);
+    MUGIQ_CHECK_NCCL(g_api.GroupEnd());
+  }
   return MUGIQ_HIP_SUCCESS;
 }
 int cb_sendrecv(void *ctx, const void *send_d, void *recv_d, size_t bytes, int dim, int dir, void *stream) {
@@ -140,6 +292,10 @@ int cb_sendrecv(void *ctx, const void *send_d, void *recv_d, size_t bytes, int d
   if (dim < 0 || dim > 3 || (dir != 1 && dir != -1)) return mugiq::set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "mugiq_hip_rccl: sendrecv dim %d dir %d", dim, dir);
   const int dst = c->neighbour(dim, dir), src = c->neighbour(dim, -dir);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (c->multipath) {  // collected; issued over all paths when the group closes (a lone message is a group of one)
+    c->pending.push_back({send_d, recv_d, bytes, dim, dir, s});
+    return c->groupDepth > 0 ? MUGIQ_HIP_SUCCESS : flush_multipath(c);
+  }
   const bool open = c->groupDepth > 0;
   if (!open) MUGIQ_CHECK_NCCL(g_api.GroupStart());
   int r = g_api.Send(send_d, bytes, kNcclInt8, dst, c->world, s);
@@ -222,6 +378,28 @@ int finish_create(MugiqHipRcclComm *c, const int grid[4], const int partitioned[
 
 }  // namespace
 
+extern "C" int mugiq_hip_rccl_relay_plan(int rank, const int grid[4], int dim, int dir, size_t bytes, int max_ops, int *phase, int *kind,
+                                         int *peer, size_t *offset, size_t *len, size_t *bounce_bytes) {
+  if (!grid || dim < 0 || dim > 3 || (dir != 1 && dir != -1)) return -MUGIQ_HIP_ERROR_INVALID_ARGUMENT;
+  std::vector<RelayOp> ops;
+  relay_plan(rank, grid, dim, dir, bytes, ops, bounce_bytes);
+  for (int i = 0; i < (int)ops.size() && i < max_ops; i++) {
+    if (phase) phase[i] = ops[i].phase;
+    if (kind) kind[i] = ops[i].kind;
+    if (peer) peer[i] = ops[i].peer;
+    if (offset) offset[i] = ops[i].offset;
+    if (len) len[i] = ops[i].len;
+  }
+  return (int)ops.size();
+}
+
+extern "C" int mugiq_hip_rccl_comm_set_multipath(MugiqHipRcclComm *c, int on) {
+  MUGIQ_REQUIRE(c != nullptr, "mugiq_hip_rccl_comm_set_multipath: NULL communicator");
+  MUGIQ_REQUIRE(c->groupDepth == 0 && c->pending.empty(), "mugiq_hip_rccl_comm_set_multipath: inside a transfer group");
+  c->multipath = on != 0 && c->size > 2;
+  return MUGIQ_HIP_SUCCESS;
+}
+
 extern "C" {
 
 int mugiq_hip_rccl_get_unique_id(void *id128_out) {
@@ -301,6 +479,7 @@ int mugiq_hip_rccl_comm_destroy(MugiqHipRcclComm *c) {
   }
   for (int i = 0; i < 2; i++)
     if (c->stage[i]) (void)hipFree(c->stage[i]);
+  if (c->bounce) (void)hipFree(c->bounce);
   if (g_api.lib) {
     if (c->space) (void)g_api.CommDestroy(c->space);
     if (c->time) (void)g_api.CommDestroy(c->time);
