@@ -528,6 +528,10 @@ int mugiq_hip_loop_entry_derived_from(const MugiqHipLoop *loop, int id);
 /* After mugiq_hip_loop_compute: the displacement entry whose pass over the eigenvectors also produced the ultra-local loop
  * (mugiq_hip_displaced_loop_contraction_fused_carry), or -1 if the ultra-local loop took a pass of its own. */
 int mugiq_hip_loop_ultra_local_carrier(const MugiqHipLoop *loop);
+/* After mugiq_hip_loop_compute: the number of posted halos whose face layers were written by the entry that runs first, on its way
+ * through the eigenvectors, instead of by mugiq_hip_pack_face_layers beside it (fp64 FLOAT2, first entry along x on the row tile,
+ * z / t partitioned; MUGIQ_HIP_PACK_IN_ENTRY=0 switches it off).  0: none; -1: bad handle / nothing computed yet. */
+int mugiq_hip_loop_halos_packed_in_entry(const MugiqHipLoop *loop);
 /* Phase timing of a compute (measurement aid; off by default).  When switched on, mugiq_hip_loop_compute brackets each
  * phase with a pair of HIP events on the stream the phase runs on and, after its final synchronisation, reports the
  * device time between them.  Phases of different streams overlap in time (that is the point of the halo stream). */

@@ -143,6 +143,7 @@ SIGNATURES = {
     "mugiq_hip_loop_get_entry": (ctypes.c_int, [_VP, ctypes.c_int, _I4]),
     "mugiq_hip_loop_entry_derived_from": (ctypes.c_int, [_VP, ctypes.c_int]),
     "mugiq_hip_loop_ultra_local_carrier": (ctypes.c_int, [_VP]),
+    "mugiq_hip_loop_halos_packed_in_entry": (ctypes.c_int, [_VP]),
     "mugiq_hip_loop_data_pos_d": (_VP, [_VP]),
     "mugiq_hip_loop_data_pos_h": (_VP, [_VP]),
     "mugiq_hip_loop_data_mom_bcast_h": (_VP, [_VP]),

@@ -42,7 +42,9 @@ namespace mugiq {
 //   TJ = 12, LN = 16: 192 sites, 12 + Kmax <= 16 staged positions, 1 + Kmax/12
 // 4-site groups: TJ LN / 4, an equal share per wave (2 | 2 | 3), group -> (position, 4 consecutive lines).
 constexpr int kMT_Waves = 16;
-constexpr int kMT_MaxSlots = 4;   // 3 displaced slots + the ultra-local loop riding along (k = 0)
+constexpr int kMT_MaxSlots = 4;   // 3 displaced slots + the ultra-local loop riding along (k = 0) per launch
+constexpr int kMT_MaxLength = 8;  // lengths 1 .. 8 per entry (launches of three lengths; 4 x 32 tiles: 1 .. 4)
+constexpr int kMT_MaxPack = 4;   // face-layer targets a row-tile launch can fill on the way (z and t, low and high side)
 constexpr int kMT_Chunk = 68;     // complex elements per chunk: 64 + 4 of bank phase
 constexpr int kMT_Chunks = 4 * 12;  // chunks of a tile buffer: 64 / LN positions each, 12 components, <= 4 * 64 / LN staged positions
 constexpr int kMT_BufElems = kMT_Chunks * kMT_Chunk;
@@ -58,7 +60,8 @@ struct MTileArgs {
   int64_t parity_offset;
   const Cplx<double> *G;  // the axial gauge: [9][J + kmax][numCols] (sign +: position j | sign -: position j + kmax)
   int k[kMT_MaxSlots];
-  int kmax;
+  int kmax;       // largest length of THIS launch (staged window: TJ + kmax positions)
+  int kmaxG;      // largest length of the entry: the axial gauge is continued that far (G holds J + kmaxG positions per line)
   int partitioned;
   const double *ghost;
   int64_t ghost_vec_stride;
@@ -72,6 +75,15 @@ struct MTileArgs {
   int overwrite;  // store instead of accumulate (MUGIQ_HIP_REGION_OVERWRITE)
   int rowsPerTile;  // mu = x: whole x rows per workgroup (R), and the chunk stride of their LDS image
   int rowChunk;
+  // mu = x only: face layers of partitioned z / t axes written on the way through (the raw eigenvector is in registers between
+  // its fetch and its rotation): what mugiq_hip_pack_face_layers would read once more, [n][layer][parity][12][faceCB]
+  int nPack;
+  struct Pack {
+    Cplx<double> *base;
+    int64_t vecStride;  // layers * 24 * faceCB
+    int dim, high, layers, faceCB;
+    int from;  // eigenvectors from .. nVec - 1 (the first halo block may have gone out ahead, packed by its own kernel)
+  } pack[kMT_MaxPack];
 };
 
 // line `cid` of direction mu: parity and checkerboard index of its j = 0 site
@@ -88,7 +100,7 @@ __host__ __device__ inline void mt_line(int cid, int H, int strideMu, int J, int
 // E_k(x) is W_k(x)[i][j]): one thread per line, sequential along the line
 struct AxialArgs {
   Cplx<double> *G;
-  const Cplx<double> *E[4];  // E_1 .. E_kmax
+  const Cplx<double> *E[kMT_MaxLength];  // E_1 .. E_kmax
   int kmax, sign, J, strideMu, H, numCols, volumeCB;
   int rowMode, X1, X2;  // mu = x: line = x row `cid`, site j <-> (parity p0 ^ (j & 1), entry cid J/2 + j/2); G is [9][row][position]
 };
@@ -168,12 +180,14 @@ __global__ __launch_bounds__(64) void axial_gauge_kernel(AxialArgs a) {
 }
 
 #define MUGIQ_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f64_4x4x4f64(a_, b_, c_, 0, 0, 0)
+// ... with the left operand negated by the instruction (for the f64 forms the BLGP field holds the NEG bits of A, B, C)
+#define MUGIQ_MFMA_NEGA(a_, b_, c_) __builtin_amdgcn_mfma_f64_4x4x4f64(a_, b_, c_, 0, 0, 1)
 
 // mu = x (DIR == 0, "row tile"): the lines run along the coalescing direction, so a workgroup owns R whole x rows (both
 // parities; R X0 = 128 | 192 sites, TJ = 0 and LN = 16 * groups per wave in the template) and there is no halo at all: the
 // positions past the end of the row (sign +) or before its start (sign -) are the row's own first / last sites, staged a
 // second time with the continued gauge g(J + l) | g(-l).  LDS image: chunk (parity, component) = [row][X0/2 + 2] complex.
-template <int DIR, int SIGN, int NS, int TJ, int LN>
+template <int DIR, int SIGN, int NS, int TJ, int LN, bool PACK = false>
 __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile_displaced_contract_kernel(MTileArgs a) {  // 4 waves per SIMD: <= 128 VGPRs
   constexpr bool kRow = DIR == 0;
   constexpr int kWaves = kRow ? TJ : kMT_Waves;  // (row tile: the TJ slot of the template carries the waves per workgroup, 8 | 16)
@@ -203,6 +217,7 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
   const bool stages = kRow || spp < NP;  // (wave-uniform: the waves of the unused positions only compute)
 
   int soff = 0, cstride = a.stride;
+  unsigned sByte = 0;  // (row tile) byte offset of this thread's first colour in an eigenvector body
   bool fromGhost = false;
   Cplx<double> g[9];
 #pragma unroll
@@ -211,8 +226,23 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
   const int compStride = kRow ? a.rowChunk : kMT_Chunk;  // distance of two components in the LDS image
   constexpr int bufElems = kWaves == 8 ? kMT_BufElems / 2 : kMT_BufElems;  // one tile buffer (two 8-wave workgroups share a CU's LDS)
   bool commits = stages;
-  // row tile: rows of X0/2 entries per parity, + 2 slots for the continued positions (element m <-> position 2 (m - off) + delta)
-  const int EPR = a.X[0] >> 1, EPRX = EPR + 2, rOff = SIGN == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : 2;
+  // (row tile, PACK) this thread's (component << 20) | entry within the (y, x) plane of a face, or -1; everything else of the pack
+  // addressing is per workgroup (its rows share z and t) and is told to the compiler to be: scalar registers, scalar arithmetic
+  int pkAB = -1;
+  uint64_t pkBase[kMT_MaxPack];  // target i at (layer, other coordinate) of this workgroup's rows, 0 = its rows are not on that face
+  if constexpr (PACK) {
+    const int zt = (blk * a.rowsPerTile) / a.X[1], zz = zt % a.X[2], tt = zt / a.X[2];
+#pragma unroll
+    for (int i = 0; i < kMT_MaxPack; i++) {
+      const int isZ = a.pack[i].dim == 2, coord = isZ ? zz : tt, other = isZ ? tt : zz;
+      const int layer = a.pack[i].high ? a.X[isZ ? 2 : 3] - 1 - coord : coord;
+      const bool member = i < a.nPack && layer < a.pack[i].layers;
+      const uint64_t p = member ? reinterpret_cast<uint64_t>(a.pack[i].base + (int64_t)layer * 24 * a.pack[i].faceCB + (int64_t)other * a.X[1] * (a.X[0] >> 1)) : 0;
+      pkBase[i] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(p >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p);
+    }
+  }
+  // row tile: rows of X0/2 entries per parity, + 4 slots for the continued positions (element m <-> position 2 (m - off) + delta)
+  const int EPR = a.X[0] >> 1, EPRX = EPR + kMT_MaxLength / 2, rOff = SIGN == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : kMT_MaxLength / 2;
   auto row_delta = [&](int rowG, int parity) {  // x of the first entry of (row, parity): (parity + y + z + t) & 1
     const int y = rowG % a.X[1], zt = rowG / a.X[1];
     return (parity + y + zt % a.X[2] + zt / a.X[2]) & 1;
@@ -227,22 +257,27 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
     const bool valid = t < nItems && (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS ? (j < J + a.kmax) : (j >= -a.kmax && j < J));
     const int jv = valid ? j : row_delta(rowG, parity);  // (invalid items fetch the first entry of their row and commit nothing)
     const int js = jv < 0 ? jv + J : (jv >= J ? jv - J : jv);  // J is even: the wrapped site has the same parity
-    const int jext = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? jv : jv + a.kmax;
-    const int Jext = J + a.kmax;
+    const int jext = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? jv : jv + a.kmaxG;
+    const int Jext = J + a.kmaxG;
     const int par = parity;
 #pragma unroll
     for (int c = 0; c < 9; c++) g[c] = a.G[((int64_t)c * a.numCols + rowG) * Jext + jext];
     soff = (int)((int64_t)par * a.parity_offset + (int64_t)(3 * spin) * a.stride + (int64_t)rowG * EPR + (js >> 1));
     wIdx = (parity * 12 + 3 * spin) * a.rowChunk + row * EPRX + mm;
     commits = valid;
+    sByte = (unsigned)soff * 16u;  // (< 2^32: mfma_tile_applicable)
+    if constexpr (PACK) {  // the R rows of a workgroup share z and t (X1 % R == 0, checked by the launcher)
+      const int m = mm - rOff;  // a real position of the row (not a continued one): this thread owns the site
+      if (valid && m >= 0 && m < EPR) pkAB = ((parity * 12 + 3 * spin) << 20) | ((rowG % a.X[1]) * EPR + m);
+    }
   } else if (stages) {
     int cid = cc * kMT_Cols + sline;
     if (cid >= a.numCols) cid = a.numCols - 1;  // surplus lines shadow the last one (valid addresses, result dropped)
     int p0, base;
     mt_line(cid, a.H, a.strideMu, J, p0, base);
     int j = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? j0 + spp : j0 - a.kmax + spp;
-    const int jext = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? j : j + a.kmax;
-    const int Jext = J + a.kmax;
+    const int jext = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? j : j + a.kmaxG;
+    const int Jext = J + a.kmaxG;
 #pragma unroll
     for (int c = 0; c < 9; c++) g[c] = a.G[((int64_t)c * Jext + jext) * a.numCols + cid];
     const int par = p0 ^ (j & 1);
@@ -266,19 +301,17 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
   const int lo = lane & 3, b = (lane >> 2) & 3, hi = lane >> 4;
   const int compRd = 3 * lo + (hi < 2 ? hi : 2);  // component 3 spin + colour (the padding lanes hi = 3 re-read colour 2)
   auto elemIdx = [&](int pp, int line) { return ((pp / kPPC) * 12 + compRd) * kMT_Chunk + (pp % kPPC) * kMT_Cols + line; };
-  int vIdx[kMT_Groups], pIdx[kMT_Groups][NS];
+  int vIdx[kMT_Groups], pIdx[kMT_Groups][kRow ? 1 : NS];  // (row tile: pIdx[gi][0] = the odd-length base, see below)
 #pragma unroll
   for (int gi = 0; gi < kMT_Groups; gi++) {
     if constexpr (kRow) {  // group = 4 consecutive entries of one (parity, row)
       const int R = a.rowsPerTile, gid = wave * kMT_Groups + gi, gpr = EPR / 4;
       const int m0 = 4 * (gid % gpr), pr = gid / gpr, parity = pr / R, row = pr - parity * R;
       const int j = 2 * (m0 + b) + row_delta(blk * R + row, parity);
+      // the shifted partner of length k: same parity plane and k / 2 entries on for an even k; the other plane and (k -+ 1) / 2 +
+      // (x of the row's first entry) on for an odd one -- two bases per group and a per-slot constant instead of NS addresses
       vIdx[gi] = (parity * 12 + compRd) * a.rowChunk + row * EPRX + m0 + b + rOff;
-#pragma unroll
-      for (int s = 0; s < NS; s++) {
-        const int js = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? j + a.k[s] : j - a.k[s];
-        pIdx[gi][s] = ((parity ^ (a.k[s] & 1)) * 12 + compRd) * a.rowChunk + row * EPRX + ((js + 2 * rOff) >> 1);
-      }
+      pIdx[gi][0] = ((parity ^ 1) * 12 + compRd) * a.rowChunk + row * EPRX + m0 + b + rOff + (j & 1);
       continue;
     }
     const int gid = wave * kMT_Groups + gi, gpos = gid / kGP, gline = 4 * (gid % kGP) + b;
@@ -286,7 +319,20 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
 #pragma unroll
     for (int s = 0; s < NS; s++) pIdx[gi][s] = elemIdx((SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? gpos + a.k[s] : a.kmax + gpos - a.k[s], gline);
   }
-  const double colourMask = hi < 3 ? 1.0 : 0.0;  // the padded colour of the left operand is ZERO (the right one may hold anything finite)
+  int rowOdd = 0, rowShift[NS];  // (row tile) bit s: length k[s] is odd; entries from the base to the partner of slot s
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    const int k = a.k[s];
+    rowOdd |= (k & 1) << s;
+    rowShift[s] = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? ((k & 1) ? (k - 1) / 2 : k / 2) : ((k & 1) ? -(k + 1) / 2 : -k / 2);
+  }
+  // the padded colour (lanes hi == 3) of the LEFT operand is zero: those lanes read a cell behind the tile buffers that holds 0 (the
+  // right operand may hold anything finite there)
+  constexpr int zeroCell = 2 * bufElems > 16 * kSites ? 2 * bufElems : 16 * kSites;  // (the launcher allocates one cell more)
+  if (t == 0) tileBase[zeroCell] = Cplx<double>{0.0, 0.0};
+#pragma unroll
+  for (int gi = 0; gi < kMT_Groups; gi++)
+    if (hi == 3) vIdx[gi] = zeroCell;
 
   double aR[kMT_Groups][NS], aI[kMT_Groups][NS];
 #pragma unroll
@@ -300,18 +346,42 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
 #define MUGIQ_MT_SIGMA(n_) as_constant(a.inv_sigma)[n_]
   // this thread's three colours of eigenvector n_ (unconditional for the staging waves: a known number of loads in flight)
 #define MUGIQ_MT_FETCH(bodyExpr_, n_, stage)                                                                           \
-  if (stages) {                                                                                                        \
-    const Cplx<double> *src_ = (fromGhost ? ghostBase + (int64_t)(n_)*a.ghost_vec_stride : (bodyExpr_)) + soff;        \
-    _Pragma("unroll") for (int c = 0; c < 3; c++) stage[c] = *as_global(reinterpret_cast<const vec2 *>(src_ + (int64_t)c * cstride)); \
+  {                                                                                                                    \
+    if constexpr (kRow) { /* scalar base + one 32-bit byte offset per lane: no 64-bit address arithmetic per lane */    \
+      const char *b_ = reinterpret_cast<const char *>(bodyExpr_);                                                      \
+      _Pragma("unroll") for (int c = 0; c < 3; c++) stage[c] = *as_global(reinterpret_cast<const vec2 *>(b_ + (int64_t)c * a.stride * 16 + (uint64_t)sByte)); \
+    } else if (stages) {                                                                                               \
+      const Cplx<double> *src_ = (fromGhost ? ghostBase + (int64_t)(n_)*a.ghost_vec_stride : (bodyExpr_)) + soff;      \
+      _Pragma("unroll") for (int c = 0; c < 3; c++) stage[c] = *as_global(reinterpret_cast<const vec2 *>(src_ + (int64_t)c * cstride)); \
+    }                                                                                                                  \
   }
   // v' = g v into tile buffer buf_
-#define MUGIQ_MT_COMMIT(stage, buf_)                                                                                   \
-  if (commits) {                                                                                                       \
-    Cplx<double> *dst_ = (buf_) + wIdx;                                                                                \
-    _Pragma("unroll") for (int i = 0; i < 3; i++) {                                                                    \
-      Cplx<double> r{0.0, 0.0};                                                                                        \
-      _Pragma("unroll") for (int j = 0; j < 3; j++) cmadd(r, g[i * 3 + j], Cplx<double>{stage[j].x, stage[j].y});      \
-      dst_[i * compStride] = r;                                                                                        \
+#define MUGIQ_MT_COMMIT(stage, buf_, n_)                                                                               \
+  {                                                                                                                    \
+    if (commits) {                                                                                                     \
+      Cplx<double> *dst_ = (buf_) + wIdx;                                                                              \
+      _Pragma("unroll") for (int i = 0; i < 3; i++) {                                                                  \
+        Cplx<double> r{0.0, 0.0};                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 3; j++) cmadd(r, g[i * 3 + j], Cplx<double>{stage[j].x, stage[j].y});    \
+        dst_[i * compStride] = r;                                                                                      \
+      }                                                                                                                \
+    }                                                                                                                  \
+    if constexpr (PACK) { /* the raw eigenvector n_ onto the face-layer targets this workgroup's rows lie on */         \
+      _Pragma("unroll") for (int i = 0; i < kMT_MaxPack; i++) {                                                        \
+        if (pkBase[i] != 0) { /* (wave-uniform.  The target's numbers come from the kernel arguments HERE, behind an index the \
+                                 compiler cannot see through: hoisted out of the eigenvector loop they cost 30 scalar registers \
+                                 and the kernel spills) */                                                             \
+          int o_ = 0;                                                                                                  \
+          asm volatile("" : "+s"(o_));                                                                                 \
+          const MTileArgs::Pack &t_ = a.pack[i + o_];                                                                  \
+          if ((n_) < t_.from || (n_) >= a.nVec) continue;                                                              \
+          char *pk_ = reinterpret_cast<char *>(pkBase[i]) + (int64_t)(n_)*t_.vecStride * 16;                           \
+          if (pkAB >= 0) {                                                                                             \
+            const unsigned f_ = (unsigned)t_.faceCB, v_ = (unsigned)(pkAB >> 20) * f_ + (unsigned)(pkAB & 0xfffff);    \
+            _Pragma("unroll") for (int c = 0; c < 3; c++) *as_global(reinterpret_cast<vec2 *>(pk_ + (uint64_t)((v_ + (unsigned)c * f_) * 16u))) = stage[c]; \
+          }                                                                                                            \
+        }                                                                                                              \
+      }                                                                                                                \
     }                                                                                                                  \
   }
 #define MUGIQ_MT_BARRIER()                              \
@@ -324,16 +394,18 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
 #define MUGIQ_MT_COMPUTE(tile_, s_)                                                                                    \
   {                                                                                                                    \
     const Cplx<double> *tile = tile_;                                                                                  \
-    const double sc = (s_)*colourMask;                                                                                 \
+    const double sc = (s_);                                                                                            \
     _Pragma("unroll") for (int gi = 0; gi < kMT_Groups; gi++) {                                                        \
       const Cplx<double> v = tile[vIdx[gi]];                                                                           \
-      const double VR = sc * v.re, VI = sc * v.im, nVI = -VI;                                                          \
+      const double VR = sc * v.re, VI = sc * v.im;                                                                     \
       _Pragma("unroll") for (int s = 0; s < NS; s++) {                                                                 \
-        const Cplx<double> p = tile[pIdx[gi][s]];                                                                      \
+        int sh_ = kRow ? rowShift[s] : 0, odd_ = kRow ? (rowOdd >> s) & 1 : 0;                                         \
+        if constexpr (kRow) asm volatile("" : "+s"(sh_), "+s"(odd_)); /* (keeps the NS x groups sums out of registers) */ \
+        const Cplx<double> p = tile[kRow ? (odd_ ? pIdx[gi][0] : vIdx[gi]) + sh_ : pIdx[gi][kRow ? 0 : s]];            \
         aR[gi][s] = MUGIQ_MFMA(VR, p.re, aR[gi][s]);                                                                   \
         aI[gi][s] = MUGIQ_MFMA(VR, p.im, aI[gi][s]);                                                                   \
         aR[gi][s] = MUGIQ_MFMA(VI, p.im, aR[gi][s]);                                                                   \
-        aI[gi][s] = MUGIQ_MFMA(nVI, p.re, aI[gi][s]);                                                                  \
+        aI[gi][s] = MUGIQ_MFMA_NEGA(VI, p.re, aI[gi][s]);                                                              \
       }                                                                                                                \
     }                                                                                                                  \
   }
@@ -350,7 +422,7 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
       sigPre = MUGIQ_MT_SIGMA(ns_);                                                                                    \
     }                                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    if (GUARD == 0 || (n_) + 1 < a.nVec) MUGIQ_MT_COMMIT(stage, tileBase + (size_t)(((n_) + 1) & 1) * bufElems)        \
+    if (GUARD == 0 || (n_) + 1 < a.nVec) MUGIQ_MT_COMMIT(stage, tileBase + (size_t)(((n_) + 1) & 1) * bufElems, (n_) + 1)        \
     if (GUARD == 0 || (n_) + 3 < a.nVec) MUGIQ_MT_FETCH(bodyNow, (n_) + 3, stage)                                      \
     MUGIQ_MT_COMPUTE(tileBase + (size_t)((n_) & 1) * bufElems, sNow)                                                   \
     MUGIQ_MT_BARRIER()                                                                                                 \
@@ -359,7 +431,7 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
   {
     const int last = a.nVec - 1;
     MUGIQ_MT_FETCH(MUGIQ_MT_BODY(0), 0, stageB)
-    MUGIQ_MT_COMMIT(stageB, tileBase)
+    MUGIQ_MT_COMMIT(stageB, tileBase, 0)
     MUGIQ_MT_FETCH(MUGIQ_MT_BODY((1 < last ? 1 : last)), (1 < last ? 1 : last), stageA)
     MUGIQ_MT_FETCH(MUGIQ_MT_BODY((2 < last ? 2 : last)), (2 < last ? 2 : last), stageB)
   }
@@ -425,6 +497,7 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
 #undef MUGIQ_MT_BARRIER
 }
 #undef MUGIQ_MFMA
+#undef MUGIQ_MFMA_NEGA
 
 // The tile geometry for an entry: the first TJ of {8, 12, 4} that divides the extent and keeps TJ + Kmax within the staged
 // positions of its line count (MUGIQ_HIP_MFMA_TJ = 4 | 8 | 12 fixes it); 0 = none.
@@ -451,8 +524,8 @@ static bool mfma_row_geometry(const MugiqHipSpinorField &ev, int *groups, int *r
     for (int g : {3, 2}) {
       if ((2 * g * w) % epr != 0) continue;
       const int r = 2 * g * w / epr;
-      if (nRows % r != 0 || r * 8 * (epr + 2) > 64 * w) continue;
-      if (24 * ((r * (epr + 2) + 11) / 16 * 16 + 4) > (w == 8 ? kMT_BufElems / 2 : kMT_BufElems)) continue;  // the LDS image of a tile buffer
+      if (nRows % r != 0 || r * 8 * (epr + kMT_MaxLength / 2) > 64 * w) continue;
+      if (24 * ((r * (epr + kMT_MaxLength / 2) + 11) / 16 * 16 + 4) > (w == 8 ? kMT_BufElems / 2 : kMT_BufElems)) continue;  // the LDS image of a tile buffer
       *groups = g;
       *rows = r;
       *waves = w;
@@ -479,11 +552,12 @@ bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, const int *kva
   for (int i = 0; i < nK; i++)
     if (kvals[i] != i + 1) return false;  // W_1 .. W_Kmax, all of them, in order
   const int kmax = nK;
-  if (kmax > kMT_MaxSlots - 1 || kmax > ev.X[dir]) return false;
+  if (kmax > kMT_MaxLength || kmax > ev.X[dir]) return false;
   if (dir == 0) {  // whole x rows: no ghost handling
     int g, r, w;
     if (const char *e = getenv("MUGIQ_HIP_MFMA_ROW"))
       if (atoi(e) == 0) return false;
+    if (2 * (int64_t)ev.parity_offset >= (1LL << 28)) return false;  // (the row tile keeps 32-bit BYTE offsets)
     return !partitioned && mfma_row_geometry(ev, &g, &r, &w);
   }
   return mfma_tile_tj(ev.X[dir], kmax) != 0;
@@ -492,7 +566,7 @@ bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, const int *kva
 static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, int rowGroups, int rowWaves, hipStream_t stream) {
   const int ln = tj == 4 ? 32 : 16;
   const size_t bufElems = dir == 0 && rowWaves == 8 ? kMT_BufElems / 2 : kMT_BufElems;
-  const size_t shmem = std::max(2 * bufElems, (size_t)16 * (dir == 0 ? 4 * rowGroups * rowWaves : tj * ln)) * sizeof(Cplx<double>);
+  const size_t shmem = (std::max(2 * bufElems, (size_t)16 * (dir == 0 ? 4 * rowGroups * rowWaves : tj * ln)) + 1) * sizeof(Cplx<double>);  // (+ the zero cell)
   const unsigned nblocks = dir == 0 ? (unsigned)(a.numCols / a.rowsPerTile) : (unsigned)(((a.numCols + ln - 1) / ln) * a.jtCount);
   a.blockOrder = 2;
   if (const char *e = getenv("MUGIQ_HIP_TILE_ORDER")) a.blockOrder = atoi(e) & 2;
@@ -501,9 +575,9 @@ static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, int 
 #define MUGIQ_MT_ROW(S, N)                                                                                             \
   {                                                                                                                    \
     if (rowWaves == 8) {                                                                                               \
-      if (rowGroups == 3) MUGIQ_MT_LAUNCH_(0, S, N, 8, 48) else MUGIQ_MT_LAUNCH_(0, S, N, 8, 32)                       \
+      if (rowGroups == 3) MUGIQ_MT_LAUNCH_P(0, S, N, 8, 48) else MUGIQ_MT_LAUNCH_P(0, S, N, 8, 32)                     \
     } else {                                                                                                           \
-      if (rowGroups == 3) MUGIQ_MT_LAUNCH_(0, S, N, 16, 48) else MUGIQ_MT_LAUNCH_(0, S, N, 16, 32)                     \
+      if (rowGroups == 3) MUGIQ_MT_LAUNCH_P(0, S, N, 16, 48) else MUGIQ_MT_LAUNCH_P(0, S, N, 16, 32)                   \
     }                                                                                                                  \
   }
 #define MUGIQ_MT_ROWCASE(S)                                                                                            \
@@ -520,6 +594,12 @@ static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, int 
     MUGIQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, a);                                                           \
   }
+#define MUGIQ_MT_LAUNCH_P(D, S, N, T, LL)                                                                              \
+  {                                                                                                                    \
+    auto kern = a.nPack > 0 ? mfma_tile_displaced_contract_kernel<D, S, N, T, LL, true> : mfma_tile_displaced_contract_kernel<D, S, N, T, LL, false>; \
+    MUGIQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+    hipLaunchKernelGGL(kern, grid, block, shmem, stream, a);                                                           \
+  }
 #define MUGIQ_MT_CASE(D, S)                                                                                            \
   case (D)*2 + (S):                                                                                                    \
     if (ns == 1) MUGIQ_MT_LAUNCH(D, S, 1) else if (ns == 2) MUGIQ_MT_LAUNCH(D, S, 2) else if (ns == 3) MUGIQ_MT_LAUNCH(D, S, 3) else MUGIQ_MT_LAUNCH(D, S, 4) \
@@ -533,6 +613,7 @@ static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, int 
 #undef MUGIQ_MT_CASE
 #undef MUGIQ_MT_LAUNCH
 #undef MUGIQ_MT_LAUNCH_
+#undef MUGIQ_MT_LAUNCH_P
 #undef MUGIQ_MT_ROW
 #undef MUGIQ_MT_ROWCASE
   MUGIQ_CHECK_HIP(hipGetLastError());
@@ -546,6 +627,34 @@ struct AxialHint {
 };
 thread_local AxialHint g_hint;
 }  // namespace
+
+namespace {
+struct PackHint {
+  int n = 0;
+  bool taken = false;
+  EntryPackTarget t[kMT_MaxPack];
+};
+thread_local PackHint g_pack;
+}  // namespace
+
+// Face layers the next mu = x entry of this host thread writes on its way through the eigenvectors (see MTileArgs::pack).
+// entry_pack_capacity: how many targets such an entry can take (0: it cannot -- not the row tile, or rows of a workgroup would
+// straddle a z / t coordinate); entry_pack_taken: did the entry launched since the last set_entry_pack_hint do it?
+int entry_pack_capacity(const MugiqHipSpinorField &ev, const int *kvals, int nK) {
+  if (const char *e = getenv("MUGIQ_HIP_PACK_IN_ENTRY"))
+    if (atoi(e) == 0) return 0;
+  if (!mfma_tile_applicable(ev, 0, kvals, nK, 0)) return 0;
+  int g, r, w;
+  if (!mfma_row_geometry(ev, &g, &r, &w) || ev.X[1] % r != 0) return 0;
+  if ((int64_t)ev.X[1] * (ev.X[0] / 2) >= (1 << 20)) return 0;  // (face entry within its (z | t) slice: 20 bits in the kernel)
+  return kMT_MaxPack;
+}
+void set_entry_pack_hint(const EntryPackTarget *targets, int n) {
+  g_pack.n = targets ? std::min(n, kMT_MaxPack) : 0;
+  g_pack.taken = false;
+  for (int i = 0; i < g_pack.n; i++) g_pack.t[i] = targets[i];
+}
+bool entry_pack_taken() { return g_pack.taken; }
 
 void set_axial_gauge_hint(const void *G_d, const void *E1_d, int dir, int sign, int kmax) {
   g_hint.G = G_d;
@@ -563,7 +672,7 @@ size_t axial_gauge_bytes(const MugiqHipSpinorField &ev, int dir, const int *kval
 int build_axial_gauge(void *G_d, const MugiqHipSpinorField &ev, const void *const *E_d, int kmax, int dir, int sign, hipStream_t stream) {
   AxialArgs g;
   g.G = static_cast<Cplx<double> *>(G_d);
-  for (int l = 0; l < 4; l++) g.E[l] = static_cast<const Cplx<double> *>(E_d[l < kmax ? l : 0]);
+  for (int l = 0; l < kMT_MaxLength; l++) g.E[l] = static_cast<const Cplx<double> *>(E_d[l < kmax ? l : 0]);
   long long strideMu = 1;
   for (int d = 0; d < dir; d++) strideMu *= ev.X[d];
   g.kmax = kmax;
@@ -623,7 +732,7 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
   a.rowsPerTile = a.rowChunk = 0;
   if (dir == 0) {
     MUGIQ_REQUIRE(mfma_row_geometry(ev[0], &rowGroups, &a.rowsPerTile, &rowWaves), "mfma tile: no row geometry for X0 = %d (internal)", ev[0].X[0]);
-    a.rowChunk = (a.rowsPerTile * (ev[0].X[0] / 2 + 2) + 11) / 16 * 16 + 4;  // >= R (X0/2 + 2), and 4 mod 16 entries: 16 banks of phase per component
+    a.rowChunk = (a.rowsPerTile * (ev[0].X[0] / 2 + kMT_MaxLength / 2) + 11) / 16 * 16 + 4;  // >= R (X0/2 + 4), and 4 mod 16 entries: 16 banks of phase per component
     MUGIQ_REQUIRE(24 * a.rowChunk <= (rowWaves == 8 ? kMT_BufElems / 2 : kMT_BufElems), "mfma tile: row image of %d entries per chunk does not fit (internal)", a.rowChunk);
     ultra_d = nullptr;  // (the row tile takes no fourth slot)
     tj = ev[0].X[0];    // one "tile" along mu
@@ -635,47 +744,72 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
   a.overwrite = (region & MUGIQ_HIP_REGION_OVERWRITE) ? 1 : 0;
   region &= 0xff;
   if (region != MUGIQ_HIP_REGION_ALL) ultra_d = nullptr;
-  a.kmax = nK;  // (mfma_tile_applicable: the lengths are 1 .. nK)
+  a.kmaxG = nK;  // (mfma_tile_applicable: the lengths are 1 .. nK)
   // the axial gauge of this (direction, sign): the caller's, if it has built one from these links; else rebuilt into the stream's
   // workspace (one pass over W_1)
-  if (g_hint.G && g_hint.E1 == E_d[0] && g_hint.dir == dir && g_hint.sign == sign && g_hint.kmax == a.kmax) {
+  if (g_hint.G && g_hint.E1 == E_d[0] && g_hint.dir == dir && g_hint.sign == sign && g_hint.kmax == a.kmaxG) {
     a.G = static_cast<const Cplx<double> *>(g_hint.G);
   } else {
     void *gbuf = nullptr;
-    if ((st = stream_workspace(&gbuf, (size_t)9 * (ev[0].X[dir] + a.kmax) * a.numCols * sizeof(Cplx<double>), stream))) return st;
-    if ((st = build_axial_gauge(gbuf, ev[0], E_d, a.kmax, dir, sign, stream))) return st;
+    if ((st = stream_workspace(&gbuf, (size_t)9 * (ev[0].X[dir] + a.kmaxG) * a.numCols * sizeof(Cplx<double>), stream))) return st;
+    if ((st = build_axial_gauge(gbuf, ev[0], E_d, a.kmaxG, dir, sign, stream))) return st;
     a.G = static_cast<const Cplx<double> *>(gbuf);
   }
-  int ns = nK;
-  for (int s = 0; s < kMT_MaxSlots; s++) {
-    const int i = s < ns ? s : 0;
-    a.k[s] = kvals[i];
-    a.out[s] = static_cast<Cplx<double> *>(loop_d) + (int64_t)i * slot_stride;
-  }
-  bool withUltra = false;
-  if (ultra_d) {
-    a.k[ns] = 0;
-    a.out[ns] = static_cast<Cplx<double> *>(ultra_d);
-    ns++;
-    withUltra = true;
-  }
-  // region 0: everything | 1: tiles whose shifted reads stay inside the local lattice | 2: tiles that read ghost layers
-  a.jtBegin = 0;
-  a.jtCount = nJT;
-  if (region != MUGIQ_HIP_REGION_ALL) {
-    const int nb = partitioned ? std::min(nJT, (a.kmax + tj - 1) / tj) : 0;  // boundary tiles
-    if (region == MUGIQ_HIP_REGION_INTERIOR) {
-      a.jtBegin = sign == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : nb;
-      a.jtCount = nJT - nb;
-    } else {
-      a.jtBegin = sign == MUGIQ_HIP_DISP_SIGN_PLUS ? nJT - nb : 0;
-      a.jtCount = nb;
+  // launches of up to four slots each (the first one may carry the ultra-local loop as its fourth); a launch of lengths
+  // k0 .. k1 stages the TJ + k1 positions its sites and their shifted partners live on
+  for (int first = 0, ns = 0; first < nK; first += ns) {
+    const bool takesUltra = ultra_d && first == 0;
+    const int room = dir == 0 ? kMT_MaxSlots - 1 : kMT_MaxSlots;  // (the row tile has no four-slot instance)
+    const int slotsLeft = nK - first + (takesUltra ? 1 : 0), launchesLeft = (slotsLeft + room - 1) / room;
+    ns = (slotsLeft + launchesLeft - 1) / launchesLeft - (takesUltra ? 1 : 0);  // evenly: 1 .. 8 with the ultra-local loop = 3 + 3 + 3 slots
+    a.kmax = kvals[first + ns - 1];
+    for (int s = 0; s < kMT_MaxSlots; s++) {
+      const int i = first + (s < ns ? s : 0);
+      a.k[s] = kvals[i];
+      a.out[s] = static_cast<Cplx<double> *>(loop_d) + (int64_t)i * slot_stride;
     }
-  }
-  if (a.jtCount > 0) {
-    st = launch_mfma_tile(a, dir, sign, ns, tj, rowGroups, rowWaves, stream);
-    if (st) return st;
-    if (withUltra && carried) *carried = 1;
+    bool withUltra = false;
+    int nSlots = ns;
+    if (takesUltra) {
+      a.k[nSlots] = 0;
+      a.out[nSlots] = static_cast<Cplx<double> *>(ultra_d);
+      nSlots++;
+      withUltra = true;
+    }
+    // region 0: everything | 1: tiles whose shifted reads stay inside the local lattice | 2: tiles that read ghost layers
+    // (the split is the ENTRY's -- by its longest length -- so that the launches of a region cover the same tiles)
+    a.nPack = 0;
+    if (dir == 0 && first == 0 && g_pack.n > 0 && !g_pack.taken && ev[0].X[1] % a.rowsPerTile == 0) {  // the first launch of the entry packs
+      a.nPack = g_pack.n;
+      for (int i = 0; i < g_pack.n; i++) {
+        const int fcb = ev[0].volumeCB / ev[0].X[g_pack.t[i].dim];
+        a.pack[i].base = static_cast<Cplx<double> *>(g_pack.t[i].out_d);
+        a.pack[i].dim = g_pack.t[i].dim;
+        a.pack[i].high = g_pack.t[i].high;
+        a.pack[i].layers = g_pack.t[i].layers;
+        a.pack[i].from = g_pack.t[i].fromVec;
+        a.pack[i].faceCB = fcb;
+        a.pack[i].vecStride = (int64_t)g_pack.t[i].layers * 24 * fcb;
+      }
+      g_pack.taken = true;
+    }
+    a.jtBegin = 0;
+    a.jtCount = nJT;
+    if (region != MUGIQ_HIP_REGION_ALL) {
+      const int nb = partitioned ? std::min(nJT, (a.kmaxG + tj - 1) / tj) : 0;  // boundary tiles
+      if (region == MUGIQ_HIP_REGION_INTERIOR) {
+        a.jtBegin = sign == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : nb;
+        a.jtCount = nJT - nb;
+      } else {
+        a.jtBegin = sign == MUGIQ_HIP_DISP_SIGN_PLUS ? nJT - nb : 0;
+        a.jtCount = nb;
+      }
+    }
+    if (a.jtCount > 0) {
+      st = launch_mfma_tile(a, dir, sign, nSlots, tj, rowGroups, rowWaves, stream);
+      if (st) return st;
+      if (withUltra && carried) *carried = 1;
+    }
   }
   return MUGIQ_HIP_SUCCESS;
 }

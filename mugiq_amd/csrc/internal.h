@@ -44,6 +44,21 @@ int fill_identity_links(const MugiqHipSpinorField *f, hipStream_t stream);  // d
 size_t axial_gauge_bytes(const MugiqHipSpinorField &ev, int dir, const int *kvals, int nK, int partitioned);
 int build_axial_gauge(void *G_d, const MugiqHipSpinorField &ev, const void *const *E_d, int kmax, int dir, int sign, hipStream_t stream);
 void set_axial_gauge_hint(const void *G_d, const void *E1_d, int dir, int sign, int kmax);
+
+// Face layers packed by a mu = x entry on its way through the eigenvectors (csrc/fused_mfma.hip, row tile): the driver hands the
+// targets of the halos it is about to post to the entry that runs first, instead of launching mugiq_hip_pack_face_layers beside it
+// (the pack kernels and a tile kernel that fills every CU's registers and LDS take turns, they do not overlap).  Per host thread,
+// like the axial-gauge hint.  Layout of out_d: [nVec][layers][parity][12][faceCB], what mugiq_hip_pack_face_layers writes.
+struct EntryPackTarget {
+  void *out_d;
+  int dim;     // 2 | 3
+  int high;    // 0: layers x[dim] = j | 1: x[dim] = X - 1 - j
+  int layers;
+  int fromVec;  // eigenvectors fromVec .. nVec - 1 (the ones before went out packed by mugiq_hip_pack_face_layers)
+};
+int entry_pack_capacity(const MugiqHipSpinorField &ev, const int *kvals, int nK);
+void set_entry_pack_hint(const EntryPackTarget *targets, int n);  // (NULL, 0) clears it
+bool entry_pack_taken();
 }  // namespace mugiq
 #include <vector>
 namespace mugiq {

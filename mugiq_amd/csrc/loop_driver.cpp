@@ -68,7 +68,7 @@ struct MugiqHipLoop_s {
   // halo transfers run on their own stream so they overlap the interior part of the fused contraction
   hipStream_t commStream = nullptr;
   hipStream_t packStream = nullptr;  // the face layers are packed here, block by block, while the previous block travels
-  hipEvent_t evPacked = nullptr, evHalo = nullptr;
+  hipEvent_t evPacked = nullptr, evHalo = nullptr, evEntryPacked = nullptr;
   // ---- data buffers (include/loop_mugiq.h:49-57, lib/loop_mugiq.cpp:101-158)
   long long nElemMomTotPerLoop = 0, nElemMomLocPerLoop = 0, nElemPosLocPerLoop = 0;
   long long nElemMomTot = 0, nElemMomLoc = 0, nElemPosLoc = 0, nElemPhMat = 0;
@@ -112,6 +112,8 @@ struct MugiqHipLoop_s {
     std::vector<hipEvent_t> evPackedBlk, evBlock;
     int nBlocks = 0, blockN = 0;
     bool posted = false;
+    int entryPacksFrom = -1;     // >= 0: the face layers of eigenvectors entryPacksFrom .. are written by the entry that runs first, on its
+                                 // way through the eigenvectors (csrc/fused_mfma.hip, row tile); -1: by mugiq_hip_pack_face_layers
     void *axialGauge = nullptr;  // the axial gauge of the entry, built once for all its launches (csrc/fused_mfma.hip), or NULL
     bool selfAlias = false;  // the neighbour is this rank itself (an axis of extent 1 under forced partitioning): the face layers are
                              // packed straight into the ghost buffer, no send buffer and no message (MUGIQ_HIP_SELF_HALO_COPY=1: keep them)
@@ -119,6 +121,7 @@ struct MugiqHipLoop_s {
   };
   std::vector<HaloPost> halo;   // per displacement entry
   std::vector<void *> held;     // pool buffers held until the end of the compute
+  int halosPackedInEntry = 0;   // posted halos whose face layers the first entry of the last compute wrote (0: pack kernels only)
 
   // ---- optional phase timing (mugiq_hip_loop_set_profiling): device time between two events bracketing each phase
   struct Phase {
@@ -437,6 +440,7 @@ static int ensure_comm_stream(MugiqHipLoop *lp) {
     MUGIQ_CHECK_HIP(hipStreamCreateWithFlags(&lp->commStream, hipStreamNonBlocking));
     MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&lp->evPacked, hipEventDisableTiming));
     MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&lp->evHalo, hipEventDisableTiming));
+    MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&lp->evEntryPacked, hipEventDisableTiming));
   }
   return MUGIQ_HIP_SUCCESS;
 }
@@ -477,6 +481,7 @@ static int prepare_halo(MugiqHipLoop *lp, int id) {
   // face layers were packed (12 ms at configs[2]) and no boundary tile before the last byte had landed.  MUGIQ_HIP_HALO_BLOCKS
   // fixes the number (1 = the single message of round 2).
   int nb = (int)std::min<size_t>(8, std::max<size_t>(1, (bytes + ((size_t)1 << 31) - 1) >> 31));
+  if (h.selfAlias) nb = 1;  // nothing travels: one block, one launch of the boundary tiles
   if (const char *e = getenv("MUGIQ_HIP_HALO_BLOCKS")) nb = std::max(1, std::min(64, atoi(e)));
   nb = std::min(nb, lp->nEv);
   h.blockN = (lp->nEv + nb - 1) / nb;
@@ -489,28 +494,40 @@ static int prepare_halo(MugiqHipLoop *lp, int id) {
     h.evBlock.push_back(e1);
   }
   h.posted = true;
+  h.entryPacksFrom = -1;
   return MUGIQ_HIP_SUCCESS;
 }
 
 // step 2: block b of every posted entry -- packed on the pack stream, handed to the transport on the halo stream (the entries
-// of one block inside one transfer group: different axes, different links)
-static int send_halo_block(MugiqHipLoop *lp, int b, bool grouped) {
+// of one block inside one transfer group: different axes, different links).  which: -1 every posted entry | 0 only those whose
+// block b is packed by mugiq_hip_pack_face_layers | 1 only those whose block b the first entry has written (the pack stream
+// waits for that entry; see mugiq_hip_loop_compute)
+static bool entry_packs_block(const MugiqHipLoop::HaloPost &h, int b) { return h.entryPacksFrom >= 0 && b * h.blockN >= h.entryPacksFrom; }
+static int send_halo_block(MugiqHipLoop *lp, int b, bool grouped, int which = -1) {
   int st = MUGIQ_HIP_SUCCESS;
+  auto takes = [&](const MugiqHipLoop::HaloPost &h) {
+    return h.posted && b < h.nBlocks && (which < 0 || (which == 1) == entry_packs_block(h, b));
+  };
   for (int id = 0; id < lp->nDispEntries; id++) {
     MugiqHipLoop::HaloPost &h = lp->halo[id];
-    if (!h.posted || b >= h.nBlocks) continue;
+    if (!takes(h)) continue;
     const int dir = lp->dispDir[id], sign = lp->dispSign[id], stop = lp->dispStop[id];
     const int n0 = b * h.blockN, nv = std::min(h.blockN, lp->nEv - n0);
     const size_t perVec = halo_bytes(lp, id) / (size_t)lp->nEv;
     const int high = (sign == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
-    if ((st = mugiq_hip_pack_face_layers(static_cast<char *>(h.gsend) + perVec * n0, &lp->eVecs[n0], nv, dir, high, stop, lp->packStream))) return st;
+    if (!entry_packs_block(h, b) &&
+        (st = mugiq_hip_pack_face_layers(static_cast<char *>(h.gsend) + perVec * n0, &lp->eVecs[n0], nv, dir, high, stop, lp->packStream)))
+      return st;
     MUGIQ_CHECK_HIP(hipEventRecord(h.evPackedBlk[b], lp->packStream));
     MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->commStream, h.evPackedBlk[b], 0));
   }
+  bool anyMessage = false;
+  for (int id = 0; id < lp->nDispEntries; id++) anyMessage = anyMessage || (takes(lp->halo[id]) && !lp->halo[id].selfAlias);
+  grouped = grouped && anyMessage;
   if (grouped && (st = lp->comm.group_begin(lp->comm.ctx))) return set_error(MUGIQ_HIP_ERROR_HIP, "group_begin callback failed with status %d", st);
   for (int id = 0; id < lp->nDispEntries && !st; id++) {
     MugiqHipLoop::HaloPost &h = lp->halo[id];
-    if (!h.posted || b >= h.nBlocks || h.selfAlias) continue;
+    if (!takes(h) || h.selfAlias) continue;
     const int n0 = b * h.blockN, nv = std::min(h.blockN, lp->nEv - n0);
     const size_t perVec = halo_bytes(lp, id) / (size_t)lp->nEv;
     const int high = (lp->dispSign[id] == MUGIQ_HIP_DISP_SIGN_PLUS) ? 0 : 1;
@@ -525,7 +542,7 @@ static int send_halo_block(MugiqHipLoop *lp, int b, bool grouped) {
   if (st) return st;
   for (int id = 0; id < lp->nDispEntries; id++) {
     MugiqHipLoop::HaloPost &h = lp->halo[id];
-    if (h.posted && b < h.nBlocks) MUGIQ_CHECK_HIP(hipEventRecord(h.evBlock[b], lp->commStream));
+    if (takes(h)) MUGIQ_CHECK_HIP(hipEventRecord(h.evBlock[b], lp->commStream));
   }
   return MUGIQ_HIP_SUCCESS;
 }
@@ -1332,12 +1349,12 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
     return st;
   };
   // the halos of the plan: link fields, packed face layers, one transfer group on the halo stream
-  auto post_halos = [&]() -> int {
-    const std::vector<char> &ahead = aheadFlags;
+  int phPack = -1, phHalo = -1, maxBlocks = 0;
+  bool halosPrepared = false;
+  auto prepare_halos = [&]() -> int {
     for (int id = 0; id < lp->nDispEntries; id++)
-      if (ahead[id] && (st = prepare_halo(lp, id))) return st;
+      if (aheadFlags[id] && (st = prepare_halo(lp, id))) return st;
     double haloBytes = 0;
-    int maxBlocks = 0;
     for (int id = 0; id < lp->nDispEntries; id++)
       if (lp->halo[id].posted) {
         haloBytes += (double)halo_bytes(lp, id);
@@ -1345,16 +1362,66 @@ int mugiq_hip_loop_compute(MugiqHipLoop *lp) {
       }
     // the pack stream starts where the halo stream starts (behind what the compute stream held when the compute began)
     MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->packStream, lp->evPacked, 0));
-    const int phPack = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_PREPARE, -1, lp->packStream, haloBytes);
-    const int phHalo = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_TRANSFER, -1, lp->commStream, haloBytes);
-    for (int b = 0; b < maxBlocks; b++)
-      if ((st = send_halo_block(lp, b, grouped))) return st;
+    phPack = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_PREPARE, -1, lp->packStream, haloBytes);
+    phHalo = phase_begin(lp, MUGIQ_HIP_PHASE_HALO_TRANSFER, -1, lp->commStream, haloBytes);
+    halosPrepared = true;
+    return MUGIQ_HIP_SUCCESS;
+  };
+  auto send_halos = [&](int bFirst, int whichFirst) -> int {
+    for (int b = bFirst; b < maxBlocks; b++)
+      if ((st = send_halo_block(lp, b, grouped, b == bFirst ? whichFirst : -1))) return st;
     phase_end(lp, phPack, lp->packStream);
     phase_end(lp, phHalo, lp->commStream);
     return MUGIQ_HIP_SUCCESS;
   };
-  if (earlyEntry >= 0) st = run_one(earlyEntry, postHalos);
-  if (!st && postHalos) st = post_halos();
+  // Who packs?  Pack kernels beside a tile kernel that fills every CU's registers and LDS do not overlap with it, they take turns
+  // (configs[2] per-GPU job: 12.6 ms of packing made the first entry 10 ms longer).  Where the entry that runs first is a mu = x
+  // entry on the row tile of csrc/fused_mfma.hip and the partitioned axes are z / t, that entry writes the face layers itself -- every
+  // raw eigenvector passes through its registers anyway -- and the pack kernels read nothing a second time.  The first block of a
+  // halo that really travels still goes out ahead, packed by its own kernel: the link must not wait for the entry to end.
+  // MUGIQ_HIP_PACK_IN_ENTRY = 0: pack kernels for everything.
+  std::vector<EntryPackTarget> packTargets;
+  lp->halosPackedInEntry = 0;
+  if (postHalos && earlyEntry >= 0 && lp->dispDir[earlyEntry] == 0 && lp->loopPrecision == lp->precision) {
+    std::vector<int> kv;
+    for (int k = lp->dispStart[earlyEntry]; k <= lp->dispStop[earlyEntry]; k++) kv.push_back(k);
+    const int room = entry_pack_capacity(lp->eVecs[0], kv.data(), (int)kv.size());
+    if (room > 0 && !(st = prepare_halos())) {
+      for (int id = 0; id < lp->nDispEntries && (int)packTargets.size() < room; id++) {
+        MugiqHipLoop::HaloPost &h = lp->halo[id];
+        if (!h.posted || lp->dispDir[id] < 2) continue;
+        const int from = h.selfAlias ? 0 : h.blockN;  // (a halo that travels in ONE block is packed by its kernel, ahead of the entry)
+        if (from >= lp->nEv) continue;
+        h.entryPacksFrom = from;
+        packTargets.push_back(EntryPackTarget{h.gsend, lp->dispDir[id], lp->dispSign[id] == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : 1, lp->dispStop[id], from});
+      }
+      if (packTargets.empty()) {  // nothing for the entry to do: the order of round 3 (entry first, pack kernels in its shadow)
+        st = run_one(earlyEntry, true);
+        if (!st) st = send_halos(0, -1);
+      } else {
+        st = send_halo_block(lp, 0, grouped, 0);  // first blocks that are packed by their kernels: on their way before the entry starts
+        if (!st) {
+          set_entry_pack_hint(packTargets.data(), (int)packTargets.size());
+          st = run_one(earlyEntry, true);
+          const bool taken = entry_pack_taken();
+          set_entry_pack_hint(nullptr, 0);
+          if (!st && taken) lp->halosPackedInEntry = (int)packTargets.size();
+          if (!st && !taken) st = set_error(MUGIQ_HIP_ERROR_INVALID_ARGUMENT, "computeCoarseLoop: entry %d was to write the face layers of the posted halos and did not (internal)", earlyEntry);
+        }
+        if (!st) {
+          MUGIQ_CHECK_HIP(hipEventRecord(lp->evEntryPacked, lp->stream));
+          MUGIQ_CHECK_HIP(hipStreamWaitEvent(lp->packStream, lp->evEntryPacked, 0));
+          st = send_halo_block(lp, 0, grouped, 1);
+        }
+        if (!st) st = send_halos(1, -1);
+      }
+    }
+  }
+  if (!halosPrepared && !st) {
+    if (earlyEntry >= 0) st = run_one(earlyEntry, postHalos);
+    if (!st && postHalos) st = prepare_halos();
+    if (!st && postHalos) st = send_halos(0, -1);
+  }
   for (int id : order) {
     if (st) break;
     if (id == earlyEntry) continue;
@@ -1451,6 +1518,8 @@ int mugiq_hip_loop_get_entry(const MugiqHipLoop *lp, int id, int out6[6]) {
 }
 
 int mugiq_hip_loop_ultra_local_carrier(const MugiqHipLoop *lp) { return (lp && lp->computed) ? lp->ultraCarrier : -1; }
+
+int mugiq_hip_loop_halos_packed_in_entry(const MugiqHipLoop *lp) { return (lp && lp->computed) ? lp->halosPackedInEntry : -1; }
 
 int mugiq_hip_loop_entry_derived_from(const MugiqHipLoop *lp, int id) {
   if (!lp || id < 0 || id >= lp->nDispEntries) return -2;
@@ -1552,6 +1621,7 @@ int mugiq_hip_loop_destroy(MugiqHipLoop *lp) {  // freeDataMemory, lib/loop_mugi
   for (hipEvent_t e : lp->events) (void)hipEventDestroy(e);
   if (lp->evPacked) (void)hipEventDestroy(lp->evPacked);
   if (lp->evHalo) (void)hipEventDestroy(lp->evHalo);
+  if (lp->evEntryPacked) (void)hipEventDestroy(lp->evEntryPacked);
   if (lp->commStream) (void)hipStreamDestroy(lp->commStream);
   if (lp->dataPos_d) (void)hipFree(lp->dataPos_d);
   if (lp->dataPosMP_d) (void)hipFree(lp->dataPosMP_d);

@@ -249,6 +249,11 @@ class Loop_Mugiq:
         """After computeCoarseLoop: the entry whose pass over the eigenvectors also produced the ultra-local loop, or -1."""
         return int(_lib.load().mugiq_hip_loop_ultra_local_carrier(self._handle))
 
+    def halosPackedInEntry(self):
+        """After computeCoarseLoop: how many posted halos had their face layers written by the first entry itself
+        (mugiq_hip_loop_halos_packed_in_entry) instead of by pack kernels beside it."""
+        return int(_lib.load().mugiq_hip_loop_halos_packed_in_entry(self._handle))
+
     def setProfiling(self, on=True):
         """Bracket every phase of the next computeCoarseLoop with HIP events (mugiq_hip_loop_set_profiling)."""
         _lib.check(_lib.load().mugiq_hip_loop_set_profiling(self._handle, int(bool(on))))

@@ -115,7 +115,10 @@ def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8), 
     force: axes of extent 1 on which the partitioned path is forced (MugiqHipComm.partitioned; self-neighbour).
     case "pool_tie": stop * N_ev == the local extent of the partitioned axes, so the multi-layer halo buffers have exactly the size
     of a path-link field, and the entry that runs before the halos are posted has the larger stop (more link fields than any
-    posted entry) -- the scratch pool must not hand that entry's fields to the pack stream while its kernels still run."""
+    posted entry) -- the scratch pool must not hand that entry's fields to the pack stream while its kernels still run.
+    case "pack": an entry along x first and four halos along z / t behind it: on a lattice the row tile of csrc/fused_mfma.hip takes
+    (X0 = 8, X1 = 16) the first entry writes their face layers itself; MUGIQ_TEST_EXPECT_PACKED says how many the driver must report.
+    case "long": entries of lengths 1 .. 8 (the matrix-pipe tile takes them as launches of three lengths over one axial gauge)."""
     import torch
     from util import orc, momenta_p2_le, rel_err
     dist = _init(rank, world, port)
@@ -143,6 +146,11 @@ def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8), 
         nev = 4
         disp = (["+x", "+t", "-z", "+y", "-t"], [1, 1, 1, 2, 2], [3, 2, 2, 2, 2])
         assert all(2 * nev == G[d] // grid[d] for d in (2, 3))
+    if case == "pack":                                                        # "+x" runs first and writes the face layers of the four halos
+        disp = (["+x", "+t", "-z", "+z", "-t", "+y"], [1, 1, 1, 2, 2, 1], [2, 3, 2, 3, 4, 1])   # (no entry derivable from another)
+    if case == "long":                                                        # the reference's own example: lengths 1 .. 8
+        nev = 2
+        disp = (["+x", "-x", "+y", "-z", "+t", "-t", "+z"], [1, 1, 1, 1, 1, 1, 1], [8, 7, 8, 5, 8, 4, 8])
     ev_lex, U_lex, sg = _global_problem(G, nev, 1234)
     cdt = np.complex128 if prec == 8 else np.complex64
     ev_lex = [v.astype(cdt).astype(np.complex128) for v in ev_lex]           # the inputs the GPU sees
@@ -168,6 +176,8 @@ def gpu_worker(rank, world, port, grid, prec, order, calc_type, G=(4, 4, 8, 8), 
     _check_pos(orc, comm.coord, grid, G, l, cprm, loop.dataPos_d.cpu().numpy().astype(np.complex128), pos_g, tol)
     e = rel_err(loop.dataMom_global(), mom_g)
     assert e < tol, ("dataMom", e)
+    if case == "pack":
+        assert loop.halosPackedInEntry() == int(os.environ["MUGIQ_TEST_EXPECT_PACKED"]), loop.halosPackedInEntry()
     if seed is None and calc_type == hip.LOOP_CALC_TYPE_BASIC_KERNEL:
         # the reference's own nest for two entries, call for call through the Displace mirror (its exchangeGhostVec goes through
         # `comm`, its extended gauge is built from the host QDP links): same slots as the driver's

@@ -628,6 +628,41 @@ def test_forced_partitioning_scratch_pool_size_tie(monkeypatch):
         mp.spawn(mp_workers.gpu_worker, args=(1, free_port(), (1, 1, 1, 1), 8, 2, 1, (4, 4, 8, 8), None, (0, 0, 1, 1), "pool_tie"), nprocs=1, join=True)
 
 
+@pytest.mark.parametrize("world,grid,G,force,env,expect", [
+    (1, (1, 1, 1, 1), (8, 16, 8, 8), (0, 0, 1, 1), {}, 4),                                     # own neighbour, packed in place
+    (1, (1, 1, 1, 1), (8, 16, 8, 8), (0, 0, 1, 1), {"MUGIQ_HIP_PACK_IN_ENTRY": "0"}, 0),       # ... by the pack kernels
+    (1, (1, 1, 1, 1), (8, 16, 8, 8), (0, 0, 1, 1), {"MUGIQ_HIP_SELF_HALO_COPY": "1", "MUGIQ_HIP_HALO_BLOCKS": "3"}, 4),  # messages to self
+    (1, (1, 1, 1, 1), (8, 16, 8, 8), (0, 0, 1, 1), {"MUGIQ_HIP_SELF_HALO_COPY": "1"}, 0),      # one block per halo: its kernel packs it
+    (1, (1, 1, 1, 1), (8, 16, 8, 8), (0, 0, 1, 1), {"MUGIQ_HIP_MFMA_ROW_WAVES": "8"}, 4),      # 8 rows per workgroup
+    (1, (1, 1, 1, 1), (8, 8, 8, 8), (0, 0, 1, 1), {}, 0),                                      # 16 rows per workgroup straddle z: not taken
+    (2, (1, 1, 1, 2), (8, 16, 8, 16), (0, 0, 1, 0), {"MUGIQ_HIP_HALO_BLOCKS": "2"}, 4),        # t travels (block 0 ahead), z to self
+    (4, (1, 1, 2, 2), (8, 16, 16, 16), (0, 0, 0, 0), {"MUGIQ_HIP_HALO_BLOCKS": "3"}, 4)])
+def test_first_entry_writes_the_face_layers(world, grid, G, force, env, expect, monkeypatch):
+    """OPT plan, z / t partitioned, a mu = x entry first: the row tile of csrc/fused_mfma.hip writes the face layers of the posted halos
+    on its way through the eigenvectors (loop.halosPackedInEntry() of them) instead of pack kernels reading the eigenvectors once
+    more beside it; the first block of a halo that travels is still packed by its own kernel and goes out before the entry starts.
+    Every variant against the single-domain oracle, position and momentum space."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("MUGIQ_TEST_EXPECT_PACKED", str(expect))
+    mp.spawn(mp_workers.gpu_worker, args=(world, free_port(), grid, 8, 2, 1, G, None, force, "pack"), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("world,grid,force,tj", [(1, (1, 1, 1, 1), (0, 0, 0, 0), None), (1, (1, 1, 1, 1), (0, 0, 0, 0), "4"),
+                                                 (1, (1, 1, 1, 1), (0, 0, 1, 1), None), (2, (1, 1, 1, 2), (0, 0, 0, 0), None),
+                                                 (1, (1, 1, 1, 1), (0, 1, 0, 1), None)])
+def test_lengths_one_to_eight(world, grid, force, tj, monkeypatch):
+    """"+z:1,8" is the reference's own example of an entry (its --displace-entry-string help): lengths 1 .. 8 in every direction on a
+    16.8.8.16 lattice -- whole, with z and t (y and t) forced-partitioned (8 ghost layers = the whole local extent), and on two
+    ranks along t (local extent 8).  csrc/fused_mfma.hip takes such an entry as launches of three lengths over ONE axial gauge
+    continued 8 positions past the line; with MUGIQ_HIP_MFMA_TJ=4 the 4 x 32 tile cannot (4 + 8 > 8 positions) and the vector
+    tiles run.  Against the single-domain oracle, position and momentum space."""
+    monkeypatch.setenv("MUGIQ_HIP_REFLECT", "0")
+    if tj:
+        monkeypatch.setenv("MUGIQ_HIP_MFMA_TJ", tj)
+    mp.spawn(mp_workers.gpu_worker, args=(world, free_port(), grid, 8, 2, 1, (16, 8, 8, 16), None, force, "long"), nprocs=world, join=True)
+
+
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
 def test_full_size_forced_partition_equals_unpartitioned(backend):
     """configs[2] per-GPU lattice 48.48.24.24 with z and t forced-partitioned (its 1x1x2x4 grid seen from one rank): all 8
