@@ -392,7 +392,7 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t[0])
         free_b, total_b = torch.cuda.mem_get_info(device)
-        rec = {"seconds": el, "phases": loop.phases(), "nLoop": loop.nLoop, "carrier": loop.ultraLocalCarrier(),
+        rec = {"seconds": el, "phases": loop.phases(), "nLoop": loop.nLoop, "carrier": loop.ultraLocalCarrier(), "packed_in_entry": loop.halosPackedInEntry(),
                "derived": [loop.derivedFrom(i) for i in range(loop.nDispEntries)],
                "entries": [loop.entry(i) for i in range(loop.nDispEntries)],
                "device_bytes_in_use": int(total_b - free_b), "create_seconds": create_s,      # eigenvectors + links + loop buffers + the driver's scratch / halo pool
@@ -464,8 +464,14 @@ def displaced_job(hip, device, X, nev, prec, comm, world, reps=2, p2max=9, backe
         out["halo"] = {"bytes_sent_per_rank": hb, "transfer_ms": hms, "GBps_per_rank": hb / (hms * 1e-3) / 1e9 if hms > 0 else None,
                        "prepare_ms": pms, "pack_GBps": 2 * hb / (pms * 1e-3) / 1e9 if pms > 0 else None,
                        "wait_ms_not_hidden": phase_sum(ph, "halo_wait"), "messages": len(halo),
+                       "halos_packed_by_first_entry": best.get("packed_in_entry", 0),
                        "note": "pack_GBps counts the face layers read + written by pack_layers_kernel over the prepare phase "
                                "(which also builds the path-link fields of the entry)"}
+        if best.get("packed_in_entry", 0) > 0:
+            out["halo"]["pack_GBps"] = None
+            out["halo"]["note"] = ("the face layers of %d halos were written by the entry that runs first, on its way through the eigenvectors "
+                                   "(csrc/fused_mfma.hip row tile); the prepare phase ends when that entry does and says nothing about a pack rate"
+                                   % best["packed_in_entry"])
     out["phase_ms"] = {k: phase_sum(ph, k) for k in sorted(set(p["kind"] for p in ph))}
     return out
 
@@ -517,7 +523,7 @@ def extra_forced(hip, device, nev=400, emulate_GBps=0.0):
         # same eigenvectors, same links (seed), same momenta: the partitioned code path must give the unpartitioned numbers
         out["max_rel_diff_forced_vs_unpartitioned"] = max_rel_diff(mom, ref)
         out["parity_ok"] = bool(out["max_rel_diff_forced_vs_unpartitioned"] < PARITY_TOL)
-    out["workload"] = "48x48x24x24 fp64 N_ev=%d, z and t FORCED-partitioned on one rank (self-neighbour: face layers packed straight into the ghost buffers, no xGMI), " \
+    out["workload"] = "48x48x24x24 fp64 N_ev=%d, z and t FORCED-partitioned on one rank (self-neighbour: face layers written straight into the ghost buffers by the first entry, no xGMI), " \
                       "entries %s, momentum projection p^2<=9, driver OPT plan, halos posted ahead" % (nev, ENTRIES_CFG2)
     out["forced_partition"] = [0, 0, 1, 1]
     if emulate_GBps > 0:
