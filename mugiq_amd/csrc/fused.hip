@@ -271,7 +271,7 @@ int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma,
                void *ultra_d, int *carried);
 
 // fourth generation: the same tile in an axial gauge on the fp64 matrix pipe (fp64 FLOAT2, mu = y, z, t, lengths 1 .. Kmax), csrc/fused_mfma.hip
-bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, const int *kvals, int nK, int partitioned);
+bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, const int *kvals, int nK, int partitioned, bool gaugeGiven);
 int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d, const int *kvals,
                     int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, int region, hipStream_t stream,
                     void *ultra_d, int *carried);
@@ -285,7 +285,7 @@ static int fused_entry(void *loop_d, const MugiqHipSpinorField *ev, const double
     int kmax = 0;
     for (int i = 0; i < nK; i++) kmax = kvals[i] > kmax ? kvals[i] : kmax;
     if constexpr (std::is_same<F, double>::value && std::is_same<A, double>::value && ORDER == 2) {
-      if (mfma_tile_applicable(ev[0], dir, kvals, nK, partitioned))
+      if (mfma_tile_applicable(ev[0], dir, kvals, nK, partitioned, axial_gauge_hint_matches(E_d[0], dir, sign, kmax)))
         return mfma_tile_entry(loop_d, ev, sigma, nVec, E_d, kvals, nK, dir, sign, partitioned, ghost_d, layers, region, stream, ultra_d, carried);
     }
     const bool gen2 = tile_applicable(ev[0], dir, kmax, ev[0].precision, partitioned);

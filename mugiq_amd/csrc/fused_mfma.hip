@@ -538,7 +538,7 @@ static bool mfma_row_geometry(const MugiqHipSpinorField &ev, int *groups, int *r
 // Can the axial-gauge tile take this entry?  fp64 FLOAT2 storage and loops, mu = y, z, t, lengths 1 .. Kmax (the gauge is
 // built from W_1 .. W_Kmax).  MUGIQ_HIP_TILE_MFMA = 0 switches it off (the vector tiles of csrc/fused_tile.hip /
 // fused_tile16.hip take over).
-bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, const int *kvals, int nK, int partitioned) {
+bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, const int *kvals, int nK, int partitioned, bool gaugeGiven) {
   if (const char *e = getenv("MUGIQ_HIP_TILE_MFMA"))
     if (atoi(e) == 0) return false;
   if (const char *e = getenv("MUGIQ_HIP_FUSED_TILE"))
@@ -549,9 +549,11 @@ bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, const int *kva
     if (atoi(e) == 0) return false;  // register-staged vector tile asked for
   if (ev.precision != 8 || ev.field_order != 2) return false;
   if (2 * (int64_t)ev.parity_offset >= (1LL << 31)) return false;  // the kernel keeps 32-bit element offsets
+  // lengths ascending; from 1 without a gap where the tile has to build the gauge itself (from W_1 .. W_Kmax = the links it is
+  // handed); any ascending list where the caller has built the gauge (the driver holds W_1 .. W_stop whatever the entry starts at)
   for (int i = 0; i < nK; i++)
-    if (kvals[i] != i + 1) return false;  // W_1 .. W_Kmax, all of them, in order
-  const int kmax = nK;
+    if (kvals[i] < 1 || (i > 0 && kvals[i] <= kvals[i - 1]) || (!gaugeGiven && kvals[i] != i + 1)) return false;
+  const int kmax = kvals[nK - 1];
   if (kmax > kMT_MaxLength || kmax > ev.X[dir]) return false;
   if (dir == 0) {  // whole x rows: no ghost handling
     int g, r, w;
@@ -643,7 +645,7 @@ thread_local PackHint g_pack;
 int entry_pack_capacity(const MugiqHipSpinorField &ev, const int *kvals, int nK) {
   if (const char *e = getenv("MUGIQ_HIP_PACK_IN_ENTRY"))
     if (atoi(e) == 0) return 0;
-  if (!mfma_tile_applicable(ev, 0, kvals, nK, 0)) return 0;
+  if (!mfma_tile_applicable(ev, 0, kvals, nK, 0, true)) return 0;  // (the driver builds the gauge where the lengths do not start at 1)
   int g, r, w;
   if (!mfma_row_geometry(ev, &g, &r, &w) || ev.X[1] % r != 0) return 0;
   if ((int64_t)ev.X[1] * (ev.X[0] / 2) >= (1 << 20)) return 0;  // (face entry within its (z | t) slice: 20 bits in the kernel)
@@ -665,8 +667,11 @@ void set_axial_gauge_hint(const void *G_d, const void *E1_d, int dir, int sign, 
 }
 
 size_t axial_gauge_bytes(const MugiqHipSpinorField &ev, int dir, const int *kvals, int nK, int partitioned) {
-  if (!mfma_tile_applicable(ev, dir, kvals, nK, partitioned)) return 0;
-  return (size_t)9 * (ev.X[dir] + nK) * (size_t)(2 * ev.volumeCB / ev.X[dir]) * sizeof(Cplx<double>);
+  if (!mfma_tile_applicable(ev, dir, kvals, nK, partitioned, true)) return 0;
+  return (size_t)9 * (ev.X[dir] + kvals[nK - 1]) * (size_t)(2 * ev.volumeCB / ev.X[dir]) * sizeof(Cplx<double>);
+}
+bool axial_gauge_hint_matches(const void *E0_d, int dir, int sign, int kmax) {
+  return g_hint.G && g_hint.E1 == E0_d && g_hint.dir == dir && g_hint.sign == sign && g_hint.kmax == kmax;
 }
 
 int build_axial_gauge(void *G_d, const MugiqHipSpinorField &ev, const void *const *E_d, int kmax, int dir, int sign, hipStream_t stream) {
@@ -737,19 +742,20 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
     ultra_d = nullptr;  // (the row tile takes no fourth slot)
     tj = ev[0].X[0];    // one "tile" along mu
   } else {
-    tj = mfma_tile_tj(ev[0].X[dir], nK);
-    MUGIQ_REQUIRE(tj != 0, "mfma tile: no tile geometry for extent %d, lengths 1..%d (internal)", ev[0].X[dir], nK);
+    tj = mfma_tile_tj(ev[0].X[dir], kvals[nK - 1]);
+    MUGIQ_REQUIRE(tj != 0, "mfma tile: no tile geometry for extent %d, lengths up to %d (internal)", ev[0].X[dir], kvals[nK - 1]);
   }
   const int nJT = ev[0].X[dir] / tj;
   a.overwrite = (region & MUGIQ_HIP_REGION_OVERWRITE) ? 1 : 0;
   region &= 0xff;
   if (region != MUGIQ_HIP_REGION_ALL) ultra_d = nullptr;
-  a.kmaxG = nK;  // (mfma_tile_applicable: the lengths are 1 .. nK)
+  a.kmaxG = kvals[nK - 1];  // (mfma_tile_applicable: ascending; 1 .. nK unless the caller's gauge is at hand)
   // the axial gauge of this (direction, sign): the caller's, if it has built one from these links; else rebuilt into the stream's
   // workspace (one pass over W_1)
-  if (g_hint.G && g_hint.E1 == E_d[0] && g_hint.dir == dir && g_hint.sign == sign && g_hint.kmax == a.kmaxG) {
+  if (axial_gauge_hint_matches(E_d[0], dir, sign, a.kmaxG)) {
     a.G = static_cast<const Cplx<double> *>(g_hint.G);
   } else {
+    MUGIQ_REQUIRE(a.kmaxG == nK, "mfma tile: lengths %d .. %d without the caller's axial gauge (internal)", kvals[0], a.kmaxG);
     void *gbuf = nullptr;
     if ((st = stream_workspace(&gbuf, (size_t)9 * (ev[0].X[dir] + a.kmaxG) * a.numCols * sizeof(Cplx<double>), stream))) return st;
     if ((st = build_axial_gauge(gbuf, ev[0], E_d, a.kmaxG, dir, sign, stream))) return st;

@@ -44,6 +44,7 @@ int fill_identity_links(const MugiqHipSpinorField *f, hipStream_t stream);  // d
 size_t axial_gauge_bytes(const MugiqHipSpinorField &ev, int dir, const int *kvals, int nK, int partitioned);
 int build_axial_gauge(void *G_d, const MugiqHipSpinorField &ev, const void *const *E_d, int kmax, int dir, int sign, hipStream_t stream);
 void set_axial_gauge_hint(const void *G_d, const void *E1_d, int dir, int sign, int kmax);
+bool axial_gauge_hint_matches(const void *E0_d, int dir, int sign, int kmax);  // E0_d: the first link field of the call
 
 // Face layers packed by a mu = x entry on its way through the eigenvectors (csrc/fused_mfma.hip, row tile): the driver hands the
 // targets of the halos it is about to post to the entry that runs first, instead of launching mugiq_hip_pack_face_layers beside it

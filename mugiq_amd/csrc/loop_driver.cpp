@@ -605,6 +605,26 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0, int part_sel = 0) 
     }
     return MUGIQ_HIP_SUCCESS;
   }
+  // Lengths that do not start at 1 ("-x:3"): the matrix-pipe tile cannot build its axial gauge from the links of the call (W_start ..
+  // W_stop), the driver can (it holds W_1 .. W_stop) and says so for the launches below.
+  struct GaugeScope {
+    bool on = false;
+    ~GaugeScope() {
+      if (on) set_axial_gauge_hint(nullptr, nullptr, -1, -1, 0);
+    }
+  } gaugeScope;
+  if (start > 1) {
+    const size_t gb = axial_gauge_bytes(lp->eVecs[0], dir, kv.data(), (int)kv.size(), part ? 1 : 0);
+    if (gb) {
+      void *G = nullptr;
+      std::vector<const void *> lk;
+      for (int k = 1; k <= stop; k++) lk.push_back(E[k].data);
+      if ((st = scratch_alloc(lp, &G, gb, false))) return st;
+      if ((st = build_axial_gauge(G, lp->eVecs[0], lk.data(), stop, dir, sign, lp->stream))) return st;
+      set_axial_gauge_hint(G, links[0], dir, sign, stop);
+      gaugeScope.on = true;
+    }
+  }
   // eigenvector blocks: bounded by the ghost-layer buffers when the dimension is partitioned
   int nb = lp->nEv;
   void *gsend = nullptr, *grecv = nullptr;

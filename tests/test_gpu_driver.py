@@ -802,6 +802,29 @@ def test_axial_gauge_matrix_pipe_tile_geometries(hip, monkeypatch):
     assert rel_err(got["MUGIQ_HIP_MFMA_TJ=8"], got["MUGIQ_HIP_TILE_MFMA=0"]) < 1e-13
 
 
+def test_axial_gauge_tile_lengths_not_starting_at_one(hip, monkeypatch):
+    """"-x:3" (the second entry of the reference's example string): the links of the fused call are W_3 only, the axial gauge needs
+    W_1 .. W_3 -- the driver, which holds them, builds the gauge and hands it to the matrix-pipe tile.  Entries starting at 2 .. 4
+    in every direction, unpartitioned, against the oracle and against the vector tiles."""
+    X, nev = (8, 8, 8, 16), 3
+    ev, Uo, f, U = _setup(hip, X, nev, 8, 2, 777)
+    sg = sigmas(nev)
+    entry = "+z:2,5;-x:3;+y:4;-t:2,3;+x:2,4;-z:3,8"
+    _, s, a, b = orc.parse_disp_entry_string(entry)
+    ref = orc.compute_loop_position_space(ev, sg, orc.LoopComputeParam(s, a, b), Uo, X)
+    monkeypatch.setenv("MUGIQ_HIP_REFLECT", "0")
+    got = {}
+    for mfma in ("1", "0"):
+        monkeypatch.setenv("MUGIQ_HIP_TILE_MFMA", mfma)
+        loop = hip.Loop_Mugiq(hip.MugiqLoopParam(gauge=U).set_displace_entry_string(entry), f, sg)
+        loop.computeCoarseLoop()
+        got[mfma] = loop.dataPos_d.cpu().numpy()
+        assert rel_err(got[mfma], ref) < 1e-12, mfma
+        loop.close()
+    assert rel_err(got["1"], got["0"]) < 1e-13
+    assert not np.array_equal(got["1"], got["0"])              # (two different kernels did run)
+
+
 @pytest.mark.parametrize("X", [(2, 2, 4, 8), (2, 8, 8, 8)])
 def test_row_tile_on_the_smallest_x_extent(hip, X):
     """X0 = 2 (one checkerboard entry per x-row): found by the 2500-seed sweep -- the row tile computed zero tiles along x
