@@ -501,10 +501,14 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
 
 // The tile geometry for an entry: the first TJ of {8, 12, 4} that divides the extent and keeps TJ + Kmax within the staged
 // positions of its line count (MUGIQ_HIP_MFMA_TJ = 4 | 8 | 12 fixes it); 0 = none.
-static int mfma_tile_tj(int extent, int kmax) {
+static int mfma_tile_tj(int extent, int kmax, int nSlots = kMT_MaxSlots, bool partitioned = true) {
   int want = 0;
   if (const char *e = getenv("MUGIQ_HIP_MFMA_TJ")) want = atoi(e);
-  for (int tj : {8, 12, 4}) {  // (measured: 8 positions x 16 lines beats 12 x 16 -- three groups per wave, spills with four slots -- and 4 x 32)
+  // 12 x 16 sites (1 + K/12 units staged per site) where it keeps its registers -- three groups per wave: up to three slots -- and the
+  // line is not partitioned (of 24 / 12 = 2 tiles along the line one would be a boundary tile): "+z:1,3;+t:1,3" N_ev 200 32.6 against
+  // 33.4 ms.  Else 8 x 16, then 12 x 16 (spills with four slots), then 4 x 32 (512-byte runs, but 1 + K/4 units).
+  const int first = (!partitioned && nSlots < kMT_MaxSlots) ? 12 : 8;
+  for (int tj : {first, 8, 12, 4}) {
     if (want && tj != want) continue;
     if (extent % tj != 0 || tj + kmax > (tj == 4 ? 8 : 16)) continue;
     return tj;
@@ -782,8 +786,15 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
       nSlots++;
       withUltra = true;
     }
+    // the tile of THIS launch (its slots and the positions it stages; the gauge does not depend on it)
+    int tjL = tj, nJTL = nJT;
+    if (dir != 0) {
+      const int t2 = mfma_tile_tj(ev[0].X[dir], a.kmax, nSlots, partitioned != 0);
+      if (t2) tjL = t2;
+      nJTL = ev[0].X[dir] / tjL;
+    }
     // region 0: everything | 1: tiles whose shifted reads stay inside the local lattice | 2: tiles that read ghost layers
-    // (the split is the ENTRY's -- by its longest length -- so that the launches of a region cover the same tiles)
+    // (the split is by the ENTRY's longest length, so that the interior and the boundary launch of a slot cover complementary tiles)
     a.nPack = 0;
     if (dir == 0 && first == 0 && g_pack.n > 0 && !g_pack.taken && ev[0].X[1] % a.rowsPerTile == 0) {  // the first launch of the entry packs
       a.nPack = g_pack.n;
@@ -800,19 +811,19 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
       g_pack.taken = true;
     }
     a.jtBegin = 0;
-    a.jtCount = nJT;
+    a.jtCount = nJTL;
     if (region != MUGIQ_HIP_REGION_ALL) {
-      const int nb = partitioned ? std::min(nJT, (a.kmaxG + tj - 1) / tj) : 0;  // boundary tiles
+      const int nb = partitioned ? std::min(nJTL, (a.kmaxG + tjL - 1) / tjL) : 0;  // boundary tiles
       if (region == MUGIQ_HIP_REGION_INTERIOR) {
         a.jtBegin = sign == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : nb;
-        a.jtCount = nJT - nb;
+        a.jtCount = nJTL - nb;
       } else {
-        a.jtBegin = sign == MUGIQ_HIP_DISP_SIGN_PLUS ? nJT - nb : 0;
+        a.jtBegin = sign == MUGIQ_HIP_DISP_SIGN_PLUS ? nJTL - nb : 0;
         a.jtCount = nb;
       }
     }
     if (a.jtCount > 0) {
-      st = launch_mfma_tile(a, dir, sign, nSlots, tj, rowGroups, rowWaves, stream);
+      st = launch_mfma_tile(a, dir, sign, nSlots, tjL, rowGroups, rowWaves, stream);
       if (st) return st;
       if (withUltra && carried) *carried = 1;
     }
