@@ -516,14 +516,14 @@ static int mfma_tile_tj(int extent, int kmax, int nSlots = kMT_MaxSlots, bool pa
   return 0;
 }
 
-// mu = x: R whole rows per workgroup of W waves, G = 2 | 3 groups of 4 sites per wave: R X0 = 16 G W sites.  One workgroup of 16
-// waves per CU where the rows allow, else two of 8 (MUGIQ_HIP_MFMA_ROW_WAVES = 8 | 16 fixes it).
+// mu = x: R whole rows per workgroup of W waves, G = 2 | 3 groups of 4 sites per wave: R X0 = 16 G W sites.  Two workgroups of 8
+// waves per CU where the rows allow, else one of 16 (MUGIQ_HIP_MFMA_ROW_WAVES = 8 | 16 fixes it).
 static bool mfma_row_geometry(const MugiqHipSpinorField &ev, int *groups, int *rows, int *waves) {
   const int epr = ev.X[0] / 2, nRows = ev.volumeCB / epr;
   if (epr % 4 != 0) return false;
   int want = 0;
   if (const char *e = getenv("MUGIQ_HIP_MFMA_ROW_WAVES")) want = atoi(e);
-  for (int w : {16, 8}) {  // (measured equal at X0 = 48: 11.6 ms per entry and 100 eigenvectors either way)
+  for (int w : {8, 16}) {  // (X0 = 48, N_ev 200, spill-free kernels: two workgroups of 8 waves per CU 13.1 ms per entry, one of 16 13.6)
     if (want && w != want) continue;
     for (int g : {3, 2}) {
       if ((2 * g * w) % epr != 0) continue;
