@@ -114,6 +114,11 @@ int mugiq_hip_release_stream(void *stream);
  * bandwidth of the device at hand. */
 int mugiq_hip_probe_read_bandwidth(const void *buf_d, size_t bytes, int nonTemporal, void *stream);
 
+/* Test aid (not part of the reference): overwrite the LDS of every CU with NaN bit patterns.  LDS is not cleared between kernels;
+ * a kernel that reads a cell it never wrote computes with whatever the previous kernel left there, which is usually finite.  With
+ * this call in front such a read shows up in the result (tests/test_gpu_driver.py::test_kernels_do_not_read_unwritten_lds). */
+int mugiq_hip_debug_poison_lds(void *stream);
+
 /* ---- gamma tables ------------------------------------------------------------------------------- */
 /* copyGammaCoeffStructToSymbol<Float>()  lib/contract_wrappers.cu:6-19
  * copyGammaMapStructToSymbol<Float>()    lib/contract_wrappers.cu:26-43

@@ -61,6 +61,7 @@ SIGNATURES = {
     "mugiq_hip_device_count": (ctypes.c_int, []),
     "mugiq_hip_release_stream": (ctypes.c_int, [_VP]),
     "mugiq_hip_probe_read_bandwidth": (ctypes.c_int, [_VP, ctypes.c_size_t, ctypes.c_int, _VP]),
+    "mugiq_hip_debug_poison_lds": (ctypes.c_int, [_VP]),
     "mugiq_hip_copy_gamma_coeff_to_symbol": (ctypes.c_int, [ctypes.c_int]),
     "mugiq_hip_copy_gamma_map_to_symbol": (ctypes.c_int, [ctypes.c_int]),
     "mugiq_hip_get_gamma_tables": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), _I4,

@@ -288,6 +288,7 @@ int mugiq_hip_perform_loop_contraction_batched(void *loopData_d, const MugiqHipS
 int mugiq_hip_perform_loop_contraction_batched_mixed(void *loopData_d, int loopPrecision, const MugiqHipSpinorField *eVecL_h,
                                                      const MugiqHipSpinorField *eVecR_h, const double *sigma_h, int nVec,
                                                      void *stream) {
+  if (int dbg_ = mugiq::debug_poison_lds_if_asked(static_cast<hipStream_t>(stream))) return dbg_;
   return mugiq::contract_dispatch(loopData_d, loopPrecision, eVecL_h, eVecR_h, sigma_h, nVec, stream,
                                   "performLoopContractionBatchedMixed");
 }

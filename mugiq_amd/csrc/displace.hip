@@ -215,6 +215,7 @@ extern "C" {
 int mugiq_hip_perform_covariant_displacement_vector(const MugiqHipSpinorField *dst, const MugiqHipSpinorField *src,
                                                     const MugiqHipGaugeField *gauge, int dispDir, int dispSign,
                                                     const int commDim[4], void *stream) {
+  if (int dbg_ = mugiq::debug_poison_lds_if_asked(static_cast<hipStream_t>(stream))) return dbg_;
   const char *who = "performCovariantDisplacementVector";
   int st = validate_spinor(dst, who, "dst");
   if (st) return st;

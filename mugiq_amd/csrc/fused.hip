@@ -393,6 +393,7 @@ int mugiq_hip_displaced_loop_contraction_fused_carry(void *loopData_d, int loopP
                                                      const int *kValues_h, int nK, int dispDir, int dispSign,
                                                      const int commDim[4], const void *ghostLayers_d, int layers, int region,
                                                      void *ultraLocalSlot_d, int *carried, void *stream) {
+  if (int dbg_ = mugiq::debug_poison_lds_if_asked(static_cast<hipStream_t>(stream))) return dbg_;
   if (carried) *carried = 0;
   const char *who = "mugiq_hip_displaced_loop_contraction_fused";
   MUGIQ_REQUIRE((region & 0xff) == MUGIQ_HIP_REGION_ALL || (region & 0xff) == MUGIQ_HIP_REGION_INTERIOR || (region & 0xff) == MUGIQ_HIP_REGION_BOUNDARY,

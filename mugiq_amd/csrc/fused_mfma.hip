@@ -330,9 +330,12 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
   // right operand may hold anything finite there)
   constexpr int zeroCell = 2 * bufElems > 16 * kSites ? 2 * bufElems : 16 * kSites;  // (the launcher allocates one cell more)
   if (t == 0) tileBase[zeroCell] = Cplx<double>{0.0, 0.0};
+  if constexpr (!kRow) {  // (row tile: vIdx is also the base of the even-length partners, which must stay real data -- a padded lane of the
+                          //  RIGHT operand multiplies zeros but must be finite; the left operand's address is chosen at the read)
 #pragma unroll
-  for (int gi = 0; gi < kMT_Groups; gi++)
-    if (hi == 3) vIdx[gi] = zeroCell;
+    for (int gi = 0; gi < kMT_Groups; gi++)
+      if (hi == 3) vIdx[gi] = zeroCell;
+  }
 
   double aR[kMT_Groups][NS], aI[kMT_Groups][NS];
 #pragma unroll
@@ -396,7 +399,9 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
     const Cplx<double> *tile = tile_;                                                                                  \
     const double sc = (s_);                                                                                            \
     _Pragma("unroll") for (int gi = 0; gi < kMT_Groups; gi++) {                                                        \
-      const Cplx<double> v = tile[vIdx[gi]];                                                                           \
+      int zc_ = zeroCell - (int)(tile - tileBase);                                                                     \
+      if constexpr (kRow) asm volatile("" : "+s"(zc_)); /* (the select below stays inside the loop: no register for it) */ \
+      const Cplx<double> v = tile[(kRow && hi == 3) ? zc_ : vIdx[gi]];                                                 \
       const double VR = sc * v.re, VI = sc * v.im;                                                                     \
       _Pragma("unroll") for (int s = 0; s < NS; s++) {                                                                 \
         int sh_ = kRow ? rowShift[s] : 0, odd_ = kRow ? (rowOdd >> s) & 1 : 0;                                         \

@@ -37,6 +37,9 @@ int release_stream_scratch(hipStream_t stream);
 size_t eo_dft_x_lds_bytes(int precision, const int localL[4], int nPx, int *redOffsetElems);  // momproj.hip
 int eo_dft_x_time_chunk(int precision, const int localL[4], int nPx);                            // momproj.hip: 0 = the fused x step does not apply
 int fill_identity_links(const MugiqHipSpinorField *f, hipStream_t stream);  // displace.hip
+// MUGIQ_HIP_DEBUG_POISON_LDS=1 (test aid): every compute entry point of the C ABI first overwrites the LDS of all CUs with NaN bit
+// patterns (mugiq_hip_debug_poison_lds), so that a kernel reading a cell it never wrote shows it in its result.
+int debug_poison_lds_if_asked(hipStream_t stream);
 // csrc/fused_mfma.hip.  The axial gauge of a (direction, sign) is rebuilt by every launch of the matrix-pipe tile (one pass over
 // W_1, 0.2 ms) -- unless the caller, who launches the same entry several times (the driver: interior tiles, then the boundary tiles
 // block by block), has built it once and says so: axial_gauge_bytes = 0 where that tile does not apply; the hint is per host

@@ -807,6 +807,7 @@ size_t mugiq_hip_momentum_projection_workspace(int locT, int nData, long long lo
 int mugiq_hip_momentum_projection(void *dataMom_d, const void *dataPosMP_d, const void *phaseMatrix_d, int locT, int nData,
                                   long long locV3, int Nmom, int precision, void *workspace_d, size_t workspace_bytes,
                                   void *stream) {
+  if (int dbg_ = mugiq::debug_poison_lds_if_asked(static_cast<hipStream_t>(stream))) return dbg_;
   const char *who = "performMomentumProjection";
   MUGIQ_REQUIRE(dataMom_d && dataPosMP_d && phaseMatrix_d, "%s: NULL argument", who);
   MUGIQ_REQUIRE(precision == 4 || precision == 8, "%s: Precision not supported!", who);  // lib/loop_mugiq.cpp:379
@@ -837,6 +838,7 @@ size_t mugiq_hip_momentum_projection_separable_workspace(const int *momMatrix_h,
 int mugiq_hip_momentum_projection_separable(void *dataMom_d, const void *dataPosMP_d, const int *momMatrix_h, int Nmom, int FTSign,
                                             const int localL[4], const int totalL[4], const int commCoord[4], int locT, int nData,
                                             int precision, void *workspace_d, size_t workspace_bytes, void *stream) {
+  if (int dbg_ = mugiq::debug_poison_lds_if_asked(static_cast<hipStream_t>(stream))) return dbg_;
   const char *who = "performMomentumProjection";
   MUGIQ_REQUIRE(dataMom_d && dataPosMP_d && momMatrix_h && localL && totalL, "%s: NULL argument", who);
   MUGIQ_REQUIRE(precision == 4 || precision == 8, "%s: Precision not supported!", who);  // lib/loop_mugiq.cpp:379
@@ -886,6 +888,7 @@ int mugiq_hip_convert_and_project(void *dataMom_d, const void *dataPos_d, int nD
 int mugiq_hip_convert_and_project_slots(void *dataMom_d, const void *dataPos_d, int nLoop, const int *slots_h, int nSlots,
                                         const int *momMatrix_h, int Nmom, int FTSign, const int localL[4], const int totalL[4],
                                         const int commCoord[4], int precision, void *workspace_d, size_t workspace_bytes, void *stream) {
+  if (int dbg_ = mugiq::debug_poison_lds_if_asked(static_cast<hipStream_t>(stream))) return dbg_;
   const char *who = "performMomentumProjection";
   MUGIQ_REQUIRE(dataMom_d && dataPos_d && slots_h && momMatrix_h && localL && totalL, "%s: NULL argument", who);
   MUGIQ_REQUIRE(nLoop >= 1 && nSlots >= 1 && nSlots <= nLoop, "%s: nSlots = %d of nLoop = %d", who, nSlots, nLoop);

@@ -1224,6 +1224,7 @@ extern "C" {
 
 int mugiq_hip_prolongate_batched(const MugiqHipSpinorField *fine_h, const MugiqHipCoarseField *coarse_h, int nVec,
                                  const MugiqHipTransfer *transfer, void *stream) {
+  if (int dbg_ = mugiq::debug_poison_lds_if_asked(static_cast<hipStream_t>(stream))) return dbg_;
   const char *who = "prolongateEvec";
   MUGIQ_REQUIRE(fine_h && coarse_h && nVec >= 1, "%s: NULL / empty argument", who);
   int st = validate_transfer(transfer, &coarse_h[0], who);
@@ -1250,6 +1251,7 @@ int mugiq_hip_prolongate_batched(const MugiqHipSpinorField *fine_h, const MugiqH
 
 int mugiq_hip_prolongate_coarse_batched(const MugiqHipCoarseField *out_h, const MugiqHipCoarseField *in_h, int nVec,
                                         const MugiqHipTransfer *T, void *stream) {
+  if (int dbg_ = mugiq::debug_poison_lds_if_asked(static_cast<hipStream_t>(stream))) return dbg_;
   const char *who = "prolongateEvec(coarse level)";
   MUGIQ_REQUIRE(out_h && in_h && nVec >= 1, "%s: NULL / empty argument", who);
   MUGIQ_REQUIRE(T && T->V, "%s: Transfer operator for this level does not exist!", who);  // lib/loop_mugiq.cpp:309
@@ -1285,6 +1287,7 @@ int mugiq_hip_prolongate_coarse_batched(const MugiqHipCoarseField *out_h, const 
 
 int mugiq_hip_prolongate_contract_batched(void *loopData_d, int loopPrecision, const MugiqHipCoarseField *coarse_h,
                                           const double *sigma_h, int nVec, const MugiqHipTransfer *transfer, void *stream) {
+  if (int dbg_ = mugiq::debug_poison_lds_if_asked(static_cast<hipStream_t>(stream))) return dbg_;
   const char *who = "prolongateContract";
   MUGIQ_REQUIRE(loopData_d && coarse_h && sigma_h && nVec >= 1, "%s: NULL / empty argument", who);
   int st = validate_transfer(transfer, &coarse_h[0], who);

@@ -132,6 +132,7 @@ extern "C" {
 
 int mugiq_hip_reflect_displaced_loop(void *dstSlot_d, const void *srcSlot_d, const void *ghostLayers_d, const int localL[4],
                                      int dispDir, int dstDispSign, int length, const int commDim[4], int precision, void *stream) {
+  if (int dbg_ = mugiq::debug_poison_lds_if_asked(static_cast<hipStream_t>(stream))) return dbg_;
   const char *who = "mugiq_hip_reflect_displaced_loop";
   MUGIQ_REQUIRE(dstSlot_d && srcSlot_d && localL && dstSlot_d != srcSlot_d, "%s: NULL / aliased argument", who);
   MUGIQ_REQUIRE(precision == 4 || precision == 8, "%s: Precision not supported! (%d)", who, precision);

@@ -162,7 +162,39 @@ static int launch_convert(void *out, const void *in, int nData, int volumeCB, co
 
 using namespace mugiq;
 
+namespace mugiq {
+// Fills every CU's LDS with signalling-NaN bit patterns (test aid): LDS is not cleared between kernels, so a kernel that reads a cell
+// it never wrote -- padding of a tile image, a lane of an operand that "multiplies zero anyway" -- sees whatever the last kernel left;
+// with this in front it sees NaN and the result shows it.
+__global__ __launch_bounds__(1024) void poison_lds_kernel(unsigned long long *sink, int words) {
+  extern __shared__ __align__(16) unsigned long long lds_words[];
+  for (int i = threadIdx.x; i < words; i += 1024) lds_words[i] = 0x7ff4dead7ff4deadULL;
+  __syncthreads();
+  if (words < 0) sink[0] = lds_words[threadIdx.x];  // (never: keeps the stores)
+}
+}  // namespace mugiq
+
+extern "C" int mugiq_hip_debug_poison_lds(void *stream);
+namespace mugiq {
+int debug_poison_lds_if_asked(hipStream_t stream) {
+  const char *e = getenv("MUGIQ_HIP_DEBUG_POISON_LDS");
+  if (!e || atoi(e) == 0) return MUGIQ_HIP_SUCCESS;
+  return mugiq_hip_debug_poison_lds(stream);
+}
+}  // namespace mugiq
+
 extern "C" {
+
+int mugiq_hip_debug_poison_lds(void *stream) {
+  static void *sink = nullptr;
+  if (!sink) MUGIQ_CHECK_HIP(hipMalloc(&sink, 64));
+  const int bytes = 160 * 1024 - 64;
+  MUGIQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mugiq::poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  // one workgroup owns a CU's whole LDS: 4096 of them pass over every CU many times
+  hipLaunchKernelGGL(mugiq::poison_lds_kernel, dim3(4096), dim3(1024), bytes, static_cast<hipStream_t>(stream), static_cast<unsigned long long *>(sink), bytes / 8);
+  MUGIQ_CHECK_HIP(hipGetLastError());
+  return MUGIQ_HIP_SUCCESS;
+}
 
 int mugiq_hip_create_phase_matrix(void *phaseMatrix_d, const int *momMatrix_h, long long locV3, int Nmom, int FTSign,
                                   const int localL[4], const int totalL[4], const int commCoord[4], int precision,

@@ -633,8 +633,9 @@ def test_forced_partitioning_scratch_pool_size_tie(monkeypatch):
     (1, (1, 1, 1, 1), (8, 16, 8, 8), (0, 0, 1, 1), {"MUGIQ_HIP_PACK_IN_ENTRY": "0"}, 0),       # ... by the pack kernels
     (1, (1, 1, 1, 1), (8, 16, 8, 8), (0, 0, 1, 1), {"MUGIQ_HIP_SELF_HALO_COPY": "1", "MUGIQ_HIP_HALO_BLOCKS": "3"}, 4),  # messages to self
     (1, (1, 1, 1, 1), (8, 16, 8, 8), (0, 0, 1, 1), {"MUGIQ_HIP_SELF_HALO_COPY": "1"}, 0),      # one block per halo: its kernel packs it
-    (1, (1, 1, 1, 1), (8, 16, 8, 8), (0, 0, 1, 1), {"MUGIQ_HIP_MFMA_ROW_WAVES": "8"}, 4),      # 8 rows per workgroup
-    (1, (1, 1, 1, 1), (8, 8, 8, 8), (0, 0, 1, 1), {}, 0),                                      # 16 rows per workgroup straddle z: not taken
+    (1, (1, 1, 1, 1), (8, 16, 8, 8), (0, 0, 1, 1), {"MUGIQ_HIP_MFMA_ROW_WAVES": "16"}, 4),     # 16 rows per workgroup (default: 8)
+    (1, (1, 1, 1, 1), (8, 8, 8, 8), (0, 0, 1, 1), {}, 4),                                      # 8 rows = one (z, t) per workgroup
+    (1, (1, 1, 1, 1), (8, 8, 8, 8), (0, 0, 1, 1), {"MUGIQ_HIP_MFMA_ROW_WAVES": "16"}, 0),      # 16 rows per workgroup straddle z: not taken
     (2, (1, 1, 1, 2), (8, 16, 8, 16), (0, 0, 1, 0), {"MUGIQ_HIP_HALO_BLOCKS": "2"}, 4),        # t travels (block 0 ahead), z to self
     (4, (1, 1, 2, 2), (8, 16, 16, 16), (0, 0, 0, 0), {"MUGIQ_HIP_HALO_BLOCKS": "3"}, 4)])
 def test_first_entry_writes_the_face_layers(world, grid, G, force, env, expect, monkeypatch):
@@ -900,3 +901,29 @@ def test_driver_reflects_in_momentum_space(hip, prec, order, FTSign, monkeypatch
         assert rel_err(loop.dataPos_d.cpu().numpy(), pos) < tol                 # materialised on request when it was left out
         assert rel_err(loop.dataPos, pos) < tol
         loop.close()
+
+
+@pytest.mark.parametrize("what", ["mfma_geometries", "mfma_long", "mfma_start", "random0", "random1", "random2", "random3", "random4", "random5",
+                                  "mg0", "mg1", "mg2", "mixed", "single"])
+def test_kernels_do_not_read_unwritten_lds(hip, what, monkeypatch, record_max):
+    """LDS is not cleared between kernels: a kernel that reads a cell it never wrote -- the padding of a tile image, an operand lane that
+    "multiplies zero anyway" -- computes with what the previous kernel left there, which is finite nearly always.  With
+    MUGIQ_HIP_DEBUG_POISON_LDS=1 every compute entry point first fills the LDS of all CUs with NaN patterns; the cases of the tests
+    named here must still match the oracle (a NaN anywhere fails them)."""
+    monkeypatch.setenv("MUGIQ_HIP_DEBUG_POISON_LDS", "1")
+    if what == "mfma_geometries":
+        test_axial_gauge_matrix_pipe_tile_geometries(hip, monkeypatch)
+    elif what == "mfma_long":
+        test_lengths_one_to_eight(1, (1, 1, 1, 1), (0, 0, 1, 1), None, monkeypatch)
+        test_lengths_one_to_eight(1, (1, 1, 1, 1), (0, 0, 0, 0), None, monkeypatch)
+    elif what == "mfma_start":
+        test_axial_gauge_tile_lengths_not_starting_at_one(hip, monkeypatch)
+    elif what.startswith("random"):
+        test_driver_random_shapes_both_fused_plans(hip, 7 * int(what[6:]) + 3, monkeypatch, record_max)
+    elif what.startswith("mg"):
+        test_driver_mg_coarse_path_random(hip, int(what[2:]), record_max)
+    elif what == "mixed":
+        test_driver_mixed_precision(hip, 4, "opt")
+    else:
+        test_driver_single_process_vs_oracle(hip, 8, 2, "opt")
+        test_driver_single_process_vs_oracle(hip, 4, 4, "opt")
