@@ -272,9 +272,9 @@ int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma,
 
 // fourth generation: the same tile in an axial gauge on the fp64 matrix pipe (fp64 FLOAT2, mu = y, z, t, lengths 1 .. Kmax), csrc/fused_mfma.hip
 bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, const int *kvals, int nK, int partitioned, bool gaugeGiven);
-int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d, const int *kvals,
-                    int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, int region, hipStream_t stream,
-                    void *ultra_d, int *carried);
+int mfma_tile_entry(void *loop_d, int loopPrecision, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d,
+                    const int *kvals, int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, int region,
+                    hipStream_t stream, void *ultra_d, int *carried);
 
 template <typename F, typename A, int ORDER>
 static int fused_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d,
@@ -284,10 +284,9 @@ static int fused_entry(void *loop_d, const MugiqHipSpinorField *ev, const double
   {
     int kmax = 0;
     for (int i = 0; i < nK; i++) kmax = kvals[i] > kmax ? kvals[i] : kmax;
-    if constexpr (std::is_same<F, double>::value && std::is_same<A, double>::value && ORDER == 2) {
-      if (mfma_tile_applicable(ev[0], dir, kvals, nK, partitioned, axial_gauge_hint_matches(E_d[0], dir, sign, kmax)))
-        return mfma_tile_entry(loop_d, ev, sigma, nVec, E_d, kvals, nK, dir, sign, partitioned, ghost_d, layers, region, stream, ultra_d, carried);
-    }
+    // (every storage type: the tile converts on the way into LDS and works in double; float slots are rounded once, on the way out)
+    if (mfma_tile_applicable(ev[0], dir, kvals, nK, partitioned, axial_gauge_hint_matches(E_d[0], dir, sign, kmax)))
+      return mfma_tile_entry(loop_d, (int)sizeof(A), ev, sigma, nVec, E_d, kvals, nK, dir, sign, partitioned, ghost_d, layers, region, stream, ultra_d, carried);
     const bool gen2 = tile_applicable(ev[0], dir, kmax, ev[0].precision, partitioned);
     if (tile16_applicable(ev[0], dir, kmax, ev[0].precision, partitioned, gen2))
       return tile16_entry<F, A, ORDER>(loop_d, ev, sigma, nVec, E_d, kvals, nK, dir, sign, partitioned, ghost_d, layers, region, stream);

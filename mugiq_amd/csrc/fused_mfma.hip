@@ -50,7 +50,8 @@ constexpr int kMT_Chunks = 4 * 12;  // chunks of a tile buffer: 64 / LN position
 constexpr int kMT_BufElems = kMT_Chunks * kMT_Chunk;
 
 struct MTileArgs {
-  Cplx<double> *out[kMT_MaxSlots];
+  void *out[kMT_MaxSlots];  // Cplx<double> | Cplx<float> (outFloat)
+  int outFloat;
   const void *const *L;
   const double *inv_sigma;
   int nVec;
@@ -63,7 +64,7 @@ struct MTileArgs {
   int kmax;       // largest length of THIS launch (staged window: TJ + kmax positions)
   int kmaxG;      // largest length of the entry: the axial gauge is continued that far (G holds J + kmaxG positions per line)
   int partitioned;
-  const double *ghost;
+  const void *ghost;  // ghost layers in the eigenvectors' precision and order
   int64_t ghost_vec_stride;
   int faceCB;
   int strideMu;   // x_cb distance of one step along DIR
@@ -98,18 +99,21 @@ __host__ __device__ inline void mt_line(int cid, int H, int strideMu, int J, int
 
 // ---- the axial gauge of one (direction, sign) from the path-link fields E_k = W_k (FLOAT2, pad 0; component 3 j + i of
 // E_k(x) is W_k(x)[i][j]): one thread per line, sequential along the line
-struct AxialArgs {
+template <typename F> struct AxialArgs {
   Cplx<double> *G;
-  const Cplx<double> *E[kMT_MaxLength];  // E_1 .. E_kmax
+  const Cplx<F> *E[kMT_MaxLength];  // E_1 .. E_kmax (storage precision; the gauge itself is kept in double)
   int kmax, sign, J, strideMu, H, numCols, volumeCB;
   int rowMode, X1, X2;  // mu = x: line = x row `cid`, site j <-> (parity p0 ^ (j & 1), entry cid J/2 + j/2); G is [9][row][position]
 };
-__device__ inline void mt_load_w(Cplx<double> w[9], const Cplx<double> *E, int par, int x_cb, int volumeCB) {
-  const Cplx<double> *e = E + (int64_t)par * 12 * volumeCB + x_cb;
+template <typename F> __device__ inline void mt_load_w(Cplx<double> w[9], const Cplx<F> *E, int par, int x_cb, int volumeCB) {
+  const Cplx<F> *e = E + (int64_t)par * 12 * volumeCB + x_cb;
 #pragma unroll
   for (int j = 0; j < 3; j++)
 #pragma unroll
-    for (int i = 0; i < 3; i++) w[i * 3 + j] = e[(int64_t)(j * 3 + i) * volumeCB];
+    for (int i = 0; i < 3; i++) {
+      const Cplx<F> u = e[(int64_t)(j * 3 + i) * volumeCB];
+      w[i * 3 + j] = Cplx<double>{(double)u.re, (double)u.im};
+    }
 }
 // r = x y (DAG: x y^dag)
 template <bool DAG> __device__ inline void mt_mul3(Cplx<double> r[9], const Cplx<double> x[9], const Cplx<double> y[9]) {
@@ -126,7 +130,7 @@ template <bool DAG> __device__ inline void mt_mul3(Cplx<double> r[9], const Cplx
       r[i * 3 + j] = s;
     }
 }
-__global__ __launch_bounds__(64) void axial_gauge_kernel(AxialArgs a) {
+template <typename F> __global__ __launch_bounds__(64) void axial_gauge_kernel(AxialArgs<F> a) {
   const int cid = blockIdx.x * 64 + threadIdx.x;
   if (cid >= a.numCols) return;
   int p0, base;
@@ -187,8 +191,13 @@ __global__ __launch_bounds__(64) void axial_gauge_kernel(AxialArgs a) {
 // parities; R X0 = 128 | 192 sites, TJ = 0 and LN = 16 * groups per wave in the template) and there is no halo at all: the
 // positions past the end of the row (sign +) or before its start (sign -) are the row's own first / last sites, staged a
 // second time with the continued gauge g(J + l) | g(-l).  LDS image: chunk (parity, component) = [row][X0/2 + 2] complex.
-template <int DIR, int SIGN, int NS, int TJ, int LN, bool PACK = false>
-__global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile_displaced_contract_kernel(MTileArgs a) {  // 4 waves per SIMD: <= 128 VGPRs
+template <int DIR, int SIGN, int NS, int TJ, int LN, bool PACK = false, typename F = double, int ORDER = 2>
+__global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile_displaced_contract_kernel(MTileArgs a) {
+  // F, ORDER: the eigenvectors' storage (double | float; FLOAT2 | FLOAT4).  They are converted on their way into LDS; the tile images, the
+  // gauge and the products are double whatever the storage, the slots double or float (a.outFloat)
+  static_assert(!PACK || (std::is_same<F, double>::value && ORDER == 2), "face layers are written on the way for fp64 FLOAT2 only");
+  // element k = 3 spin + colour of checkerboard entry x in a field body of stride `stride` (complex elements from the parity base)
+  auto fieldOff = [](int k, int x, int stride) { return ORDER == 2 ? k * stride + x : (((k >> 1) * stride + x) << 1) + (k & 1); };  // 4 waves per SIMD: <= 128 VGPRs
   constexpr bool kRow = DIR == 0;
   constexpr int kWaves = kRow ? TJ : kMT_Waves;  // (row tile: the TJ slot of the template carries the waves per workgroup, 8 | 16)
   constexpr int kMT_TJ = TJ, kMT_Cols = LN;
@@ -218,6 +227,7 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
 
   int soff = 0, cstride = a.stride;
   unsigned sByte = 0;  // (row tile) byte offset of this thread's first colour in an eigenvector body
+  int offC[3] = {0, 0, 0};  // (FLOAT4) element offsets of the three colours (FLOAT2: soff + c * cstride)
   bool fromGhost = false;
   Cplx<double> g[9];
 #pragma unroll
@@ -263,9 +273,11 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
 #pragma unroll
     for (int c = 0; c < 9; c++) g[c] = a.G[((int64_t)c * a.numCols + rowG) * Jext + jext];
     soff = (int)((int64_t)par * a.parity_offset + (int64_t)(3 * spin) * a.stride + (int64_t)rowG * EPR + (js >> 1));
+#pragma unroll
+    for (int c = 0; c < 3; c++) offC[c] = (int)((int64_t)par * a.parity_offset + fieldOff(3 * spin + c, rowG * EPR + (js >> 1), a.stride));
     wIdx = (parity * 12 + 3 * spin) * a.rowChunk + row * EPRX + mm;
     commits = valid;
-    sByte = (unsigned)soff * 16u;  // (< 2^32: mfma_tile_applicable)
+    sByte = (unsigned)soff * (unsigned)sizeof(Cplx<F>);  // (< 2^32: mfma_tile_applicable)
     if constexpr (PACK) {  // the R rows of a workgroup share z and t (X1 % R == 0, checked by the launcher)
       const int m = mm - rOff;  // a real position of the row (not a continued one): this thread owns the site
       if (valid && m >= 0 && m < EPR) pkAB = ((parity * 12 + 3 * spin) << 20) | ((rowG % a.X[1]) * EPR + m);
@@ -289,13 +301,17 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
       fromGhost = true;
       cstride = a.faceCB;
       soff = (int)((int64_t)layer * 24 * a.faceCB + (int64_t)par * 12 * a.faceCB + (int64_t)(3 * sspin) * a.faceCB + faceIdx);
+#pragma unroll
+      for (int c = 0; c < 3; c++) offC[c] = (int)((int64_t)layer * 24 * a.faceCB + (int64_t)par * 12 * a.faceCB + fieldOff(3 * sspin + c, faceIdx, a.faceCB));
     } else {
       j = j < 0 ? j + J : (j >= J ? j - J : j);
       soff = (int)((int64_t)par * a.parity_offset + (int64_t)(3 * sspin) * a.stride + base + j * a.strideMu);
+#pragma unroll
+      for (int c = 0; c < 3; c++) offC[c] = (int)((int64_t)par * a.parity_offset + fieldOff(3 * sspin + c, base + j * a.strideMu, a.stride));
     }
     wIdx = ((spp / kPPC) * 12 + 3 * sspin) * kMT_Chunk + (spp % kPPC) * kMT_Cols + sline;
   }
-  const Cplx<double> *ghostBase = reinterpret_cast<const Cplx<double> *>(a.ghost);
+  const Cplx<F> *ghostBase = reinterpret_cast<const Cplx<F> *>(a.ghost);
 
   // ---- arithmetic role: lane = 16 hi + 4 b + lo; group wave * G + gi = (position, line quad), site b = line 4 quad + b
   const int lo = lane & 3, b = (lane >> 2) & 3, hi = lane >> 4;
@@ -344,18 +360,26 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
     for (int s = 0; s < NS; s++) aR[gi][s] = aI[gi][s] = 0.0;
 
   typedef double vec2 __attribute__((ext_vector_type(2)));
-  vec2 stageA[3], stageB[3];
-#define MUGIQ_MT_BODY(n_) static_cast<const Cplx<double> *>(as_constant(a.L)[n_])
+  typedef F vecF __attribute__((ext_vector_type(2)));  // one complex number of the storage type
+  vecF stageA[3], stageB[3];
+#define MUGIQ_MT_BODY(n_) static_cast<const Cplx<F> *>(as_constant(a.L)[n_])
 #define MUGIQ_MT_SIGMA(n_) as_constant(a.inv_sigma)[n_]
   // this thread's three colours of eigenvector n_ (unconditional for the staging waves: a known number of loads in flight)
 #define MUGIQ_MT_FETCH(bodyExpr_, n_, stage)                                                                           \
   {                                                                                                                    \
-    if constexpr (kRow) { /* scalar base + one 32-bit byte offset per lane: no 64-bit address arithmetic per lane */    \
+    if constexpr (kRow && ORDER == 2) { /* scalar base + one 32-bit byte offset per lane: no 64-bit address arithmetic per lane */ \
       const char *b_ = reinterpret_cast<const char *>(bodyExpr_);                                                      \
-      _Pragma("unroll") for (int c = 0; c < 3; c++) stage[c] = *as_global(reinterpret_cast<const vec2 *>(b_ + (int64_t)c * a.stride * 16 + (uint64_t)sByte)); \
+      _Pragma("unroll") for (int c = 0; c < 3; c++) stage[c] = *as_global(reinterpret_cast<const vecF *>(b_ + (int64_t)c * a.stride * (int64_t)sizeof(Cplx<F>) + (uint64_t)sByte)); \
+    } else if constexpr (kRow) { /* (FLOAT4: the colours of a spin are not a stride apart) */                          \
+      const Cplx<F> *b_ = (bodyExpr_);                                                                                 \
+      _Pragma("unroll") for (int c = 0; c < 3; c++) stage[c] = *as_global(reinterpret_cast<const vecF *>(b_ + offC[c])); \
     } else if (stages) {                                                                                               \
-      const Cplx<double> *src_ = (fromGhost ? ghostBase + (int64_t)(n_)*a.ghost_vec_stride : (bodyExpr_)) + soff;      \
-      _Pragma("unroll") for (int c = 0; c < 3; c++) stage[c] = *as_global(reinterpret_cast<const vec2 *>(src_ + (int64_t)c * cstride)); \
+      const Cplx<F> *base_ = fromGhost ? ghostBase + (int64_t)(n_)*a.ghost_vec_stride : (bodyExpr_);                   \
+      if constexpr (ORDER == 2) {                                                                                      \
+        _Pragma("unroll") for (int c = 0; c < 3; c++) stage[c] = *as_global(reinterpret_cast<const vecF *>(base_ + soff + (int64_t)c * cstride)); \
+      } else {                                                                                                         \
+        _Pragma("unroll") for (int c = 0; c < 3; c++) stage[c] = *as_global(reinterpret_cast<const vecF *>(base_ + offC[c])); \
+      }                                                                                                                \
     }                                                                                                                  \
   }
   // v' = g v into tile buffer buf_
@@ -365,7 +389,7 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
       Cplx<double> *dst_ = (buf_) + wIdx;                                                                              \
       _Pragma("unroll") for (int i = 0; i < 3; i++) {                                                                  \
         Cplx<double> r{0.0, 0.0};                                                                                      \
-        _Pragma("unroll") for (int j = 0; j < 3; j++) cmadd(r, g[i * 3 + j], Cplx<double>{stage[j].x, stage[j].y});    \
+        _Pragma("unroll") for (int j = 0; j < 3; j++) cmadd(r, g[i * 3 + j], Cplx<double>{(double)stage[j].x, (double)stage[j].y}); \
         dst_[i * compStride] = r;                                                                                      \
       }                                                                                                                \
     }                                                                                                                  \
@@ -420,7 +444,7 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
 #define MUGIQ_MT_STEP(n_, stage, GUARD)                                                                                \
   {                                                                                                                    \
     const double sNow = sigPre;                                                                                        \
-    const Cplx<double> *bodyNow = bodyPre;                                                                             \
+    const Cplx<F> *bodyNow = bodyPre;                                                                                  \
     {                                                                                                                  \
       const int nb_ = (n_) + 4 < a.nVec ? (n_) + 4 : a.nVec - 1, ns_ = (n_) + 1 < a.nVec ? (n_) + 1 : a.nVec - 1;      \
       bodyPre = MUGIQ_MT_BODY(nb_);                                                                                    \
@@ -440,7 +464,7 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
     MUGIQ_MT_FETCH(MUGIQ_MT_BODY((1 < last ? 1 : last)), (1 < last ? 1 : last), stageA)
     MUGIQ_MT_FETCH(MUGIQ_MT_BODY((2 < last ? 2 : last)), (2 < last ? 2 : last), stageB)
   }
-  const Cplx<double> *bodyPre = MUGIQ_MT_BODY(a.nVec > 3 ? 3 : a.nVec - 1);
+  const Cplx<F> *bodyPre = MUGIQ_MT_BODY(a.nVec > 3 ? 3 : a.nVec - 1);
   double sigPre = MUGIQ_MT_SIGMA(0);
   MUGIQ_MT_BARRIER()
   int n = 0;
@@ -494,8 +518,32 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
 #pragma unroll
       for (int e = 0; e < 16; e++) full[e] = scratch[e * kSites + site];
       const int siteIdx = xmine + pmine * a.volumeCB;
-      if (half == 0) trace_and_store_range<double, 0, 8>(a.out[s], full, 2 * a.volumeCB, siteIdx, a.overwrite != 0);
-      else trace_and_store_range<double, 8, 16>(a.out[s], full, 2 * a.volumeCB, siteIdx, a.overwrite != 0);
+      if (std::is_same<F, double>::value || !a.outFloat) {  // (fp64 eigenvectors come with fp64 slots: no second store path in those kernels)
+        Cplx<double> *o = static_cast<Cplx<double> *>(a.out[s]);
+        if (half == 0) trace_and_store_range<double, 0, 8>(o, full, 2 * a.volumeCB, siteIdx, a.overwrite != 0);
+        else trace_and_store_range<double, 8, 16>(o, full, 2 * a.volumeCB, siteIdx, a.overwrite != 0);
+      } else {  // fp32 slots: the traces are taken in double and rounded once, on the way out
+        Cplx<double> tr[4];
+        Cplx<float> *o = static_cast<Cplx<float> *>(a.out[s]) + siteIdx;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          if (half == 0) {
+            if (q == 0) traces_range<double, 0>(tr, full);
+            else traces_range<double, 4>(tr, full);
+          } else {
+            if (q == 0) traces_range<double, 8>(tr, full);
+            else traces_range<double, 12>(tr, full);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            Cplx<float> *w = o + (int64_t)(2 * a.volumeCB) * (8 * half + 4 * q + i);
+            Cplx<float> v = a.overwrite ? Cplx<float>{0.f, 0.f} : *w;
+            v.re += (float)tr[i].re;
+            v.im += (float)tr[i].im;
+            *w = v;
+          }
+        }
+      }
     }
     if (s + 1 < NS) MUGIQ_MT_BARRIER()
   }
@@ -506,7 +554,7 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
 
 // The tile geometry for an entry: the first TJ of {8, 12, 4} that divides the extent and keeps TJ + Kmax within the staged
 // positions of its line count (MUGIQ_HIP_MFMA_TJ = 4 | 8 | 12 fixes it); 0 = none.
-static int mfma_tile_tj(int extent, int kmax, int nSlots = kMT_MaxSlots, bool partitioned = true) {
+static int mfma_tile_tj(int extent, int kmax, int nSlots = kMT_MaxSlots, bool partitioned = true, bool reduced = false) {
   int want = 0;
   if (const char *e = getenv("MUGIQ_HIP_MFMA_TJ")) want = atoi(e);
   // 12 x 16 sites (1 + K/12 units staged per site) where it keeps its registers -- three groups per wave: up to three slots -- and the
@@ -515,6 +563,7 @@ static int mfma_tile_tj(int extent, int kmax, int nSlots = kMT_MaxSlots, bool pa
   const int first = (!partitioned && nSlots < kMT_MaxSlots) ? 12 : 8;
   for (int tj : {first, 8, 12, 4}) {
     if (want && tj != want) continue;
+    if (reduced && tj == 4) continue;  // (storage types other than fp64 FLOAT2 come with the 16-line tiles only)
     if (extent % tj != 0 || tj + kmax > (tj == 4 ? 8 : 16)) continue;
     return tj;
   }
@@ -523,6 +572,7 @@ static int mfma_tile_tj(int extent, int kmax, int nSlots = kMT_MaxSlots, bool pa
 
 // mu = x: R whole rows per workgroup of W waves, G = 2 | 3 groups of 4 sites per wave: R X0 = 16 G W sites.  Two workgroups of 8
 // waves per CU where the rows allow, else one of 16 (MUGIQ_HIP_MFMA_ROW_WAVES = 8 | 16 fixes it).
+static bool mfma_reduced(const MugiqHipSpinorField &ev) { return !(ev.precision == 8 && ev.field_order == 2); }
 static bool mfma_row_geometry(const MugiqHipSpinorField &ev, int *groups, int *rows, int *waves) {
   const int epr = ev.X[0] / 2, nRows = ev.volumeCB / epr;
   if (epr % 4 != 0) return false;
@@ -530,6 +580,7 @@ static bool mfma_row_geometry(const MugiqHipSpinorField &ev, int *groups, int *r
   if (const char *e = getenv("MUGIQ_HIP_MFMA_ROW_WAVES")) want = atoi(e);
   for (int w : {8, 16}) {  // (X0 = 48, N_ev 200, spill-free kernels: two workgroups of 8 waves per CU 13.1 ms per entry, one of 16 13.6)
     if (want && w != want) continue;
+    if (mfma_reduced(ev) && w != 8) continue;  // (... and with the 8-wave row tile only)
     for (int g : {3, 2}) {
       if ((2 * g * w) % epr != 0) continue;
       const int r = 2 * g * w / epr;
@@ -556,7 +607,9 @@ bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, const int *kva
     if (atoi(e) != 0) return false;  // a vector-tile generation was asked for by name
   if (const char *e = getenv("MUGIQ_HIP_TILE_GLDS"))
     if (atoi(e) == 0) return false;  // register-staged vector tile asked for
-  if (ev.precision != 8 || ev.field_order != 2) return false;
+  if ((ev.precision != 8 && ev.precision != 4) || (ev.field_order != 2 && ev.field_order != 4)) return false;
+  if (const char *e = getenv("MUGIQ_HIP_MFMA_STORAGE"))
+    if (atoi(e) == 0 && mfma_reduced(ev)) return false;  // fp64 FLOAT2 only, as before
   if (2 * (int64_t)ev.parity_offset >= (1LL << 31)) return false;  // the kernel keeps 32-bit element offsets
   // lengths ascending; from 1 without a gap where the tile has to build the gauge itself (from W_1 .. W_Kmax = the links it is
   // handed); any ascending list where the caller has built the gauge (the driver holds W_1 .. W_stop whatever the entry starts at)
@@ -571,10 +624,13 @@ bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, const int *kva
     if (2 * (int64_t)ev.parity_offset >= (1LL << 28)) return false;  // (the row tile keeps 32-bit BYTE offsets)
     return !partitioned && mfma_row_geometry(ev, &g, &r, &w);
   }
-  return mfma_tile_tj(ev.X[dir], kmax) != 0;
+  return mfma_tile_tj(ev.X[dir], kmax, kMT_MaxSlots, true, mfma_reduced(ev)) != 0;
 }
 
-static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, int rowGroups, int rowWaves, hipStream_t stream) {
+// F, ORDER: the eigenvectors' storage.  FULL: every tile geometry and the face-layer packing (fp64 FLOAT2); else the 16-line column tiles
+// and the 8-wave row tile only (a sixth of the instances per storage type).
+template <typename F, int ORDER, bool FULL>
+static int launch_mfma_tile_t(MTileArgs a, int dir, int sign, int ns, int tj, int rowGroups, int rowWaves, hipStream_t stream) {
   const int ln = tj == 4 ? 32 : 16;
   const size_t bufElems = dir == 0 && rowWaves == 8 ? kMT_BufElems / 2 : kMT_BufElems;
   const size_t shmem = (std::max(2 * bufElems, (size_t)16 * (dir == 0 ? 4 * rowGroups * rowWaves : tj * ln)) + 1) * sizeof(Cplx<double>);  // (+ the zero cell)
@@ -583,11 +639,14 @@ static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, int 
   if (const char *e = getenv("MUGIQ_HIP_TILE_ORDER")) a.blockOrder = atoi(e) & 2;
   if (nblocks % 8 != 0 || dir == 0) a.blockOrder = 0;
   const dim3 grid(nblocks), block(64 * (dir == 0 ? rowWaves : kMT_Waves));
+  if (!FULL) {
+    MUGIQ_REQUIRE(a.nPack == 0 && tj != 4 && (dir != 0 || rowWaves == 8), "mfma tile: geometry %d / %d waves / %d pack targets not built for this storage type (internal)", tj, rowWaves, a.nPack);
+  }
 #define MUGIQ_MT_ROW(S, N)                                                                                             \
   {                                                                                                                    \
     if (rowWaves == 8) {                                                                                               \
       if (rowGroups == 3) MUGIQ_MT_LAUNCH_P(0, S, N, 8, 48) else MUGIQ_MT_LAUNCH_P(0, S, N, 8, 32)                     \
-    } else {                                                                                                           \
+    } else if constexpr (FULL) {                                                                                       \
       if (rowGroups == 3) MUGIQ_MT_LAUNCH_P(0, S, N, 16, 48) else MUGIQ_MT_LAUNCH_P(0, S, N, 16, 32)                   \
     }                                                                                                                  \
   }
@@ -597,17 +656,20 @@ static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, int 
     break;
 #define MUGIQ_MT_LAUNCH(D, S, N)                                                                                       \
   {                                                                                                                    \
-    if (tj == 12) MUGIQ_MT_LAUNCH_(D, S, N, 12, 16) else if (tj == 8) MUGIQ_MT_LAUNCH_(D, S, N, 8, 16) else MUGIQ_MT_LAUNCH_(D, S, N, 4, 32) \
+    if (tj == 12) MUGIQ_MT_LAUNCH_(D, S, N, 12, 16) else if (tj == 8) MUGIQ_MT_LAUNCH_(D, S, N, 8, 16) else if constexpr (FULL) MUGIQ_MT_LAUNCH_(D, S, N, 4, 32) \
   }
 #define MUGIQ_MT_LAUNCH_(D, S, N, T, LL)                                                                               \
   {                                                                                                                    \
-    auto kern = mfma_tile_displaced_contract_kernel<D, S, N, T, LL>;                                                   \
+    auto kern = mfma_tile_displaced_contract_kernel<D, S, N, T, LL, false, F, ORDER>;                                  \
     MUGIQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, a);                                                           \
   }
 #define MUGIQ_MT_LAUNCH_P(D, S, N, T, LL)                                                                              \
   {                                                                                                                    \
-    auto kern = a.nPack > 0 ? mfma_tile_displaced_contract_kernel<D, S, N, T, LL, true> : mfma_tile_displaced_contract_kernel<D, S, N, T, LL, false>; \
+    auto kern = mfma_tile_displaced_contract_kernel<D, S, N, T, LL, false, F, ORDER>;                                  \
+    if constexpr (FULL) {                                                                                              \
+      if (a.nPack > 0) kern = mfma_tile_displaced_contract_kernel<D, S, N, T, LL, FULL, F, ORDER>;                     \
+    }                                                                                                                  \
     MUGIQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, a);                                                           \
   }
@@ -629,6 +691,13 @@ static int launch_mfma_tile(MTileArgs a, int dir, int sign, int ns, int tj, int 
 #undef MUGIQ_MT_ROWCASE
   MUGIQ_CHECK_HIP(hipGetLastError());
   return MUGIQ_HIP_SUCCESS;
+}
+
+static int launch_mfma_tile(const MTileArgs &a, int precision, int order, int dir, int sign, int ns, int tj, int rowGroups, int rowWaves, hipStream_t stream) {
+  if (precision == 8 && order == 2) return launch_mfma_tile_t<double, 2, true>(a, dir, sign, ns, tj, rowGroups, rowWaves, stream);
+  if (precision == 8) return launch_mfma_tile_t<double, 4, false>(a, dir, sign, ns, tj, rowGroups, rowWaves, stream);
+  if (order == 2) return launch_mfma_tile_t<float, 2, false>(a, dir, sign, ns, tj, rowGroups, rowWaves, stream);
+  return launch_mfma_tile_t<float, 4, false>(a, dir, sign, ns, tj, rowGroups, rowWaves, stream);
 }
 
 namespace {
@@ -654,6 +723,7 @@ thread_local PackHint g_pack;
 int entry_pack_capacity(const MugiqHipSpinorField &ev, const int *kvals, int nK) {
   if (const char *e = getenv("MUGIQ_HIP_PACK_IN_ENTRY"))
     if (atoi(e) == 0) return 0;
+  if (mfma_reduced(ev)) return 0;
   if (!mfma_tile_applicable(ev, 0, kvals, nK, 0, true)) return 0;  // (the driver builds the gauge where the lengths do not start at 1)
   int g, r, w;
   if (!mfma_row_geometry(ev, &g, &r, &w) || ev.X[1] % r != 0) return 0;
@@ -683,10 +753,11 @@ bool axial_gauge_hint_matches(const void *E0_d, int dir, int sign, int kmax) {
   return g_hint.G && g_hint.E1 == E0_d && g_hint.dir == dir && g_hint.sign == sign && g_hint.kmax == kmax;
 }
 
-int build_axial_gauge(void *G_d, const MugiqHipSpinorField &ev, const void *const *E_d, int kmax, int dir, int sign, hipStream_t stream) {
-  AxialArgs g;
+template <typename F>
+static int build_axial_gauge_t(void *G_d, const MugiqHipSpinorField &ev, const void *const *E_d, int kmax, int dir, int sign, hipStream_t stream) {
+  AxialArgs<F> g;
   g.G = static_cast<Cplx<double> *>(G_d);
-  for (int l = 0; l < kMT_MaxLength; l++) g.E[l] = static_cast<const Cplx<double> *>(E_d[l < kmax ? l : 0]);
+  for (int l = 0; l < kMT_MaxLength; l++) g.E[l] = static_cast<const Cplx<F> *>(E_d[l < kmax ? l : 0]);
   long long strideMu = 1;
   for (int d = 0; d < dir; d++) strideMu *= ev.X[d];
   g.kmax = kmax;
@@ -699,16 +770,21 @@ int build_axial_gauge(void *G_d, const MugiqHipSpinorField &ev, const void *cons
   g.rowMode = dir == 0;
   g.X1 = ev.X[1];
   g.X2 = ev.X[2];
-  hipLaunchKernelGGL(axial_gauge_kernel, dim3((g.numCols + 63) / 64), dim3(64), 0, stream, g);
+  hipLaunchKernelGGL(axial_gauge_kernel<F>, dim3((g.numCols + 63) / 64), dim3(64), 0, stream, g);
   MUGIQ_CHECK_HIP(hipGetLastError());
   return MUGIQ_HIP_SUCCESS;
+}
+// (the path-link fields are FLOAT2, pad 0, in the eigenvectors' precision)
+int build_axial_gauge(void *G_d, const MugiqHipSpinorField &ev, const void *const *E_d, int kmax, int dir, int sign, hipStream_t stream) {
+  return ev.precision == 8 ? build_axial_gauge_t<double>(G_d, ev, E_d, kmax, dir, sign, stream)
+                           : build_axial_gauge_t<float>(G_d, ev, E_d, kmax, dir, sign, stream);
 }
 
 // ultra_d != NULL: also produce the ultra-local loop (k = 0) into ultra_d as one more slot; *carried says whether that
 // happened (only a launch over the whole lattice may: see csrc/fused_tile.hip)
-int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d, const int *kvals,
-                    int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, int region, hipStream_t stream,
-                    void *ultra_d, int *carried) {
+int mfma_tile_entry(void *loop_d, int loopPrecision, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d,
+                    const int *kvals, int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, int region,
+                    hipStream_t stream, void *ultra_d, int *carried) {
   const size_t ptr_bytes = sizeof(void *) * (size_t)nVec;
   std::vector<unsigned char> host(ptr_bytes + sizeof(double) * (size_t)nVec);
   const void **hl = reinterpret_cast<const void **>(host.data());
@@ -721,7 +797,8 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
   int st = upload_table(&dev, host.data(), host.size(), stream);
   if (st) return st;
   MTileArgs a;
-  const int64_t slot_stride = (int64_t)16 * 2 * ev[0].volumeCB;
+  const int64_t slot_stride = (int64_t)16 * 2 * ev[0].volumeCB * 2 * loopPrecision;  // bytes
+  a.outFloat = loopPrecision == 4;
   if (carried) *carried = 0;
   a.L = reinterpret_cast<const void *const *>(dev);
   a.inv_sigma = reinterpret_cast<const double *>(static_cast<unsigned char *>(dev) + ptr_bytes);
@@ -736,7 +813,7 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
   a.stride = ev[0].stride;
   a.parity_offset = ev[0].parity_offset;
   a.partitioned = partitioned;
-  a.ghost = static_cast<const double *>(ghost_d);
+  a.ghost = ghost_d;
   a.faceCB = ev[0].volumeCB / ev[0].X[dir];
   a.ghost_vec_stride = (int64_t)layers * 24 * a.faceCB;
   a.strideMu = (int)strideMu;
@@ -751,7 +828,7 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
     ultra_d = nullptr;  // (the row tile takes no fourth slot)
     tj = ev[0].X[0];    // one "tile" along mu
   } else {
-    tj = mfma_tile_tj(ev[0].X[dir], kvals[nK - 1]);
+    tj = mfma_tile_tj(ev[0].X[dir], kvals[nK - 1], kMT_MaxSlots, true, mfma_reduced(ev[0]));
     MUGIQ_REQUIRE(tj != 0, "mfma tile: no tile geometry for extent %d, lengths up to %d (internal)", ev[0].X[dir], kvals[nK - 1]);
   }
   const int nJT = ev[0].X[dir] / tj;
@@ -781,20 +858,20 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
     for (int s = 0; s < kMT_MaxSlots; s++) {
       const int i = first + (s < ns ? s : 0);
       a.k[s] = kvals[i];
-      a.out[s] = static_cast<Cplx<double> *>(loop_d) + (int64_t)i * slot_stride;
+      a.out[s] = static_cast<char *>(loop_d) + (int64_t)i * slot_stride;
     }
     bool withUltra = false;
     int nSlots = ns;
     if (takesUltra) {
       a.k[nSlots] = 0;
-      a.out[nSlots] = static_cast<Cplx<double> *>(ultra_d);
+      a.out[nSlots] = ultra_d;
       nSlots++;
       withUltra = true;
     }
     // the tile of THIS launch (its slots and the positions it stages; the gauge does not depend on it)
     int tjL = tj, nJTL = nJT;
     if (dir != 0) {
-      const int t2 = mfma_tile_tj(ev[0].X[dir], a.kmax, nSlots, partitioned != 0);
+      const int t2 = mfma_tile_tj(ev[0].X[dir], a.kmax, nSlots, partitioned != 0, mfma_reduced(ev[0]));
       if (t2) tjL = t2;
       nJTL = ev[0].X[dir] / tjL;
     }
@@ -828,7 +905,7 @@ int mfma_tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *s
       }
     }
     if (a.jtCount > 0) {
-      st = launch_mfma_tile(a, dir, sign, nSlots, tjL, rowGroups, rowWaves, stream);
+      st = launch_mfma_tile(a, ev[0].precision, ev[0].field_order, dir, sign, nSlots, tjL, rowGroups, rowWaves, stream);
       if (st) return st;
       if (withUltra && carried) *carried = 1;
     }

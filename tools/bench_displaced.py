@@ -18,6 +18,7 @@ ap.add_argument("--lattice", type=int, nargs=4, default=[48, 48, 24, 24])
 ap.add_argument("--nev", type=int, default=100)
 ap.add_argument("--precision", type=int, default=8)
 ap.add_argument("--order", type=int, default=2)
+ap.add_argument("--loop-precision", type=int, default=0, help="8 with --precision 4: fp32 eigenvectors, fp64 loops")
 ap.add_argument("--entries", default="+x:1,3;-x:1,3;+y:1,3;-y:1,3;+z:1,3;-z:1,3;+t:1,3;-t:1,3")
 ap.add_argument("--plans", default="opt,basic")
 ap.add_argument("--reps", type=int, default=2)
@@ -62,6 +63,8 @@ if a.ab_env:
     name, vals = a.ab_env.split("=")
     vals = vals.split(",")
     prm = hip.MugiqLoopParam(gauge=g, calcType=hip.LOOP_CALC_TYPE_OPT_KERNEL)
+    if a.loop_precision:
+        prm.loopPrecision = a.loop_precision
     prm.set_displace_entry_string(a.entries)
     loop = hip.Loop_Mugiq(prm, fields, sig)
     ts = {v: [] for v in vals}
