@@ -270,7 +270,7 @@ int tile_entry(void *loop_d, const MugiqHipSpinorField *ev, const double *sigma,
                int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, int region, hipStream_t stream,
                void *ultra_d, int *carried);
 
-// fourth generation: the same tile in an axial gauge on the fp64 matrix pipe (fp64 FLOAT2, mu = y, z, t, lengths 1 .. Kmax), csrc/fused_mfma.hip
+// fourth generation: the same tile in an axial gauge on the fp64 matrix pipe (any storage type, ascending lengths up to 8), csrc/fused_mfma.hip
 bool mfma_tile_applicable(const MugiqHipSpinorField &ev, int dir, const int *kvals, int nK, int partitioned, bool gaugeGiven);
 int mfma_tile_entry(void *loop_d, int loopPrecision, const MugiqHipSpinorField *ev, const double *sigma, int nVec, const void *const *E_d,
                     const int *kvals, int nK, int dir, int sign, int partitioned, const void *ghost_d, int layers, int region,

@@ -1,5 +1,6 @@
-// Fused displaced contraction in an axial gauge on the fp64 matrix pipe (fourth generation; fp64 FLOAT2 column tiles,
-// mu = y, z, t, lengths 1 .. Kmax).
+// Fused displaced contraction in an axial gauge on the fp64 matrix pipe (fourth generation).  Column tiles for mu = y, z, t, whole x rows
+// for mu = x; ascending lengths up to 8 per entry; eigenvectors fp64 FLOAT2 (every tile geometry, and the face layers of posted halos
+// written on the way) or fp64 FLOAT4 / fp32 FLOAT2 / fp32 FLOAT4 (converted on their way into LDS; 16-line tiles); slots fp64 or fp32.
 //
 // (1) The gauge.  Along every line of direction mu fix g(j + 1) = g(j) U_mu(x_j), g(0) = 1 (continued past both ends of
 // the local line with the path-link products the driver has anyway: g(J + l) = g(J - 1) W_{l+1}(x_{J-1}), g(-l) = W^-_l(x_0)).
