@@ -156,7 +156,7 @@ static bool mfma_row_geometry(const MugiqHipSpinorField &ev, int *groups, int *r
       if ((2 * g * w) % epr != 0) continue;
       const int r = 2 * g * w / epr;
       if (nRows % r != 0 || r * 8 * (epr + kMT_MaxLength / 2) > 64 * w) continue;
-      if (24 * ((r * (epr + kMT_MaxLength / 2) + 11) / 16 * 16 + 4) > (w == 8 ? kMT_BufElems / 2 : kMT_BufElems)) continue;  // the LDS image of a tile buffer
+      if (24 * ((r * (epr + kMT_MaxLength / 2) + 12) / 16 * 16 + 4) > (w == 8 ? kMT_BufElems / 2 : kMT_BufElems)) continue;  // the LDS image of a tile buffer
       *groups = g;
       *rows = r;
       *waves = w;
@@ -328,7 +328,7 @@ int mfma_tile_entry(void *loop_d, int loopPrecision, const MugiqHipSpinorField *
   a.rowsPerTile = a.rowChunk = 0;
   if (dir == 0) {
     MUGIQ_REQUIRE(mfma_row_geometry(ev[0], &rowGroups, &a.rowsPerTile, &rowWaves), "mfma tile: no row geometry for X0 = %d (internal)", ev[0].X[0]);
-    a.rowChunk = (a.rowsPerTile * (ev[0].X[0] / 2 + kMT_MaxLength / 2) + 11) / 16 * 16 + 4;  // >= R (X0/2 + 4), and 4 mod 16 entries: 16 banks of phase per component
+    a.rowChunk = (a.rowsPerTile * (ev[0].X[0] / 2 + kMT_MaxLength / 2) + 12) / 16 * 16 + 4;  // > R (X0/2 + 4) (the entry behind the rows holds the zero of the padded operand lanes), and 4 mod 16 entries: 16 banks of phase per component
     MUGIQ_REQUIRE(24 * a.rowChunk <= (rowWaves == 8 ? kMT_BufElems / 2 : kMT_BufElems), "mfma tile: row image of %d entries per chunk does not fit (internal)", a.rowChunk);
     ultra_d = nullptr;  // (the row tile takes no fourth slot)
     tj = ev[0].X[0];    // one "tile" along mu

@@ -205,17 +205,20 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
   const int lo = lane & 3, b = (lane >> 2) & 3, hi = lane >> 4;
   const int compRd = 3 * lo + (hi < 2 ? hi : 2);  // component 3 spin + colour (the padding lanes hi = 3 re-read colour 2)
   auto elemIdx = [&](int pp, int line) { return ((pp / kPPC) * 12 + compRd) * kMT_Chunk + (pp % kPPC) * kMT_Cols + line; };
-  int vIdx[kMT_Groups], pIdx[kMT_Groups][kRow ? 1 : NS];  // (row tile: pIdx[gi][0] = the odd-length base, see below)
+  int vIdx[kMT_Groups], pIdx[kMT_Groups][NS];
 #pragma unroll
   for (int gi = 0; gi < kMT_Groups; gi++) {
     if constexpr (kRow) {  // group = 4 consecutive entries of one (parity, row)
       const int R = a.rowsPerTile, gid = wave * kMT_Groups + gi, gpr = EPR / 4;
       const int m0 = 4 * (gid % gpr), pr = gid / gpr, parity = pr / R, row = pr - parity * R;
       const int j = 2 * (m0 + b) + row_delta(blk * R + row, parity);
-      // the shifted partner of length k: same parity plane and k / 2 entries on for an even k; the other plane and (k -+ 1) / 2 +
-      // (x of the row's first entry) on for an odd one -- two bases per group and a per-slot constant instead of NS addresses
+      // the shifted partner of length k: the same parity plane for an even k, the other one for an odd k
       vIdx[gi] = (parity * 12 + compRd) * a.rowChunk + row * EPRX + m0 + b + rOff;
-      pIdx[gi][0] = ((parity ^ 1) * 12 + compRd) * a.rowChunk + row * EPRX + m0 + b + rOff + (j & 1);
+#pragma unroll
+      for (int s = 0; s < NS; s++) {
+        const int js = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? j + a.k[s] : j - a.k[s];
+        pIdx[gi][s] = ((parity ^ (a.k[s] & 1)) * 12 + compRd) * a.rowChunk + row * EPRX + ((js + 2 * rOff) >> 1);
+      }
       continue;
     }
     const int gid = wave * kMT_Groups + gi, gpos = gid / kGP, gline = 4 * (gid % kGP) + b;
@@ -223,23 +226,14 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
 #pragma unroll
     for (int s = 0; s < NS; s++) pIdx[gi][s] = elemIdx((SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? gpos + a.k[s] : a.kmax + gpos - a.k[s], gline);
   }
-  int rowOdd = 0, rowShift[NS];  // (row tile) bit s: length k[s] is odd; entries from the base to the partner of slot s
+  // the padded colour (lanes hi == 3) of the LEFT operand is zero: those lanes read a padding entry of the first chunk of the tile
+  // image -- no commit ever writes there -- that holds 0 in BOTH buffers (the right operand may hold anything finite in its padded
+  // lanes: its addresses point at real data)
+  const int zeroCell = kRow ? a.rowChunk - 1 : 64;
+  if (t < 2) tileBase[(size_t)t * bufElems + zeroCell] = Cplx<double>{0.0, 0.0};
 #pragma unroll
-  for (int s = 0; s < NS; s++) {
-    const int k = a.k[s];
-    rowOdd |= (k & 1) << s;
-    rowShift[s] = (SIGN == MUGIQ_HIP_DISP_SIGN_PLUS) ? ((k & 1) ? (k - 1) / 2 : k / 2) : ((k & 1) ? -(k + 1) / 2 : -k / 2);
-  }
-  // the padded colour (lanes hi == 3) of the LEFT operand is zero: those lanes read a cell behind the tile buffers that holds 0 (the
-  // right operand may hold anything finite there)
-  constexpr int zeroCell = 2 * bufElems > 16 * kSites ? 2 * bufElems : 16 * kSites;  // (the launcher allocates one cell more)
-  if (t == 0) tileBase[zeroCell] = Cplx<double>{0.0, 0.0};
-  if constexpr (!kRow) {  // (row tile: vIdx is also the base of the even-length partners, which must stay real data -- a padded lane of the
-                          //  RIGHT operand multiplies zeros but must be finite; the left operand's address is chosen at the read)
-#pragma unroll
-    for (int gi = 0; gi < kMT_Groups; gi++)
-      if (hi == 3) vIdx[gi] = zeroCell;
-  }
+  for (int gi = 0; gi < kMT_Groups; gi++)
+    if (hi == 3) vIdx[gi] = zeroCell;
 
   double aR[kMT_Groups][NS], aI[kMT_Groups][NS];
 #pragma unroll
@@ -311,14 +305,10 @@ __global__ __launch_bounds__(64 * (DIR == 0 ? TJ : kMT_Waves), 4) void mfma_tile
     const Cplx<double> *tile = tile_;                                                                                  \
     const double sc = (s_);                                                                                            \
     _Pragma("unroll") for (int gi = 0; gi < kMT_Groups; gi++) {                                                        \
-      int zc_ = zeroCell - (int)(tile - tileBase);                                                                     \
-      if constexpr (kRow) asm volatile("" : "+s"(zc_)); /* (the select below stays inside the loop: no register for it) */ \
-      const Cplx<double> v = tile[(kRow && hi == 3) ? zc_ : vIdx[gi]];                                                 \
+      const Cplx<double> v = tile[vIdx[gi]];                                                                           \
       const double VR = sc * v.re, VI = sc * v.im;                                                                     \
       _Pragma("unroll") for (int s = 0; s < NS; s++) {                                                                 \
-        int sh_ = kRow ? rowShift[s] : 0, odd_ = kRow ? (rowOdd >> s) & 1 : 0;                                         \
-        if constexpr (kRow) asm volatile("" : "+s"(sh_), "+s"(odd_)); /* (keeps the NS x groups sums out of registers) */ \
-        const Cplx<double> p = tile[kRow ? (odd_ ? pIdx[gi][0] : vIdx[gi]) + sh_ : pIdx[gi][kRow ? 0 : s]];            \
+        const Cplx<double> p = tile[pIdx[gi][s]];                                                                      \
         aR[gi][s] = MUGIQ_MFMA(VR, p.re, aR[gi][s]);                                                                   \
         aI[gi][s] = MUGIQ_MFMA(VR, p.im, aI[gi][s]);                                                                   \
         aR[gi][s] = MUGIQ_MFMA(VI, p.im, aR[gi][s]);                                                                   \
@@ -446,7 +436,7 @@ template <typename F, int ORDER, bool FULL>
 inline int launch_mfma_tile_t(MTileArgs a, int dir, int sign, int ns, int tj, int rowGroups, int rowWaves, hipStream_t stream) {
   const int ln = tj == 4 ? 32 : 16;
   const size_t bufElems = dir == 0 && rowWaves == 8 ? kMT_BufElems / 2 : kMT_BufElems;
-  const size_t shmem = (std::max(2 * bufElems, (size_t)16 * (dir == 0 ? 4 * rowGroups * rowWaves : tj * ln)) + 1) * sizeof(Cplx<double>);  // (+ the zero cell)
+  const size_t shmem = std::max(2 * bufElems, (size_t)16 * (dir == 0 ? 4 * rowGroups * rowWaves : tj * ln)) * sizeof(Cplx<double>);
   const unsigned nblocks = dir == 0 ? (unsigned)(a.numCols / a.rowsPerTile) : (unsigned)(((a.numCols + ln - 1) / ln) * a.jtCount);
   a.blockOrder = 2;
   if (const char *e = getenv("MUGIQ_HIP_TILE_ORDER")) a.blockOrder = atoi(e) & 2;
