@@ -123,6 +123,78 @@ template <typename F> __global__ __launch_bounds__(64) void axial_gauge_kernel(A
   }
 }
 
+// ---- the same gauge straight from the gauge field, for a direction that is NOT partitioned (the local line is the global, periodic
+// one): W_1(x) = U_mu(x), so g(j + 1) = g(j) U_mu(x_j) for either sign, continued with the links of the wrapped sites --
+// g(J + l) = g(J + l - 1) U(x_{(J + l - 1) mod J}), g(-l) = g(-l + 1) U(x_{J - l})^dag -- and no path-link field has to be built at all
+// (the driver's chain of `stop` covariant displacements of the identity: 0.4 ms and a GB of scratch per entry at configs[2]).
+template <typename F> struct AxialLinkArgs {
+  Cplx<double> *G;
+  const Cplx<F> *U;   // extended gauge field: parity * Upo + (dir * 9 + row * 3 + col) * Ustride + x_cb on the extended lattice
+  int64_t Upo;
+  int Ustride;
+  int X[4], R[4];
+  int dir, kmax, sign, J, strideMu, H, numCols;
+  int rowMode;
+};
+template <typename F> __global__ __launch_bounds__(64) void axial_gauge_from_links_kernel(AxialLinkArgs<F> a) {
+  const int cid = blockIdx.x * 64 + threadIdx.x;
+  if (cid >= a.numCols) return;
+  int p0, base;
+  if (a.rowMode) {
+    const int zt = cid / a.X[1];
+    p0 = (cid % a.X[1] + zt % a.X[2] + zt / a.X[2]) & 1;
+    base = cid * (a.J >> 1);
+  } else {
+    mt_line(cid, a.H, a.strideMu, a.J, p0, base);
+  }
+  int c0[4], XE[4];
+  get_coords(c0, base, a.X, p0);  // the j = 0 site of the line (row mode: x = 0 or 1 -- only the other three coordinates are used)
+#pragma unroll
+  for (int d = 0; d < 4; d++) XE[d] = a.X[d] + 2 * a.R[d];
+  auto load_u = [&](Cplx<double> u[9], int j) {  // U_mu at position j of the line (0 <= j < J)
+    int c[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) c[d] = (d == a.dir ? j : c0[d]) + a.R[d];
+    const int par = p0 ^ (j & 1);  // (borders are even in sum: the extended parity is the interior one)
+    const Cplx<F> *q = a.U + (int64_t)par * a.Upo + (int64_t)(a.dir * 9) * a.Ustride + (lex_index(c, XE) >> 1);
+#pragma unroll
+    for (int e = 0; e < 9; e++) {
+      const Cplx<F> v = q[(int64_t)e * a.Ustride];
+      u[e] = Cplx<double>{(double)v.re, (double)v.im};
+    }
+  };
+  const int Jext = a.J + a.kmax;
+  auto store = [&](int jext, const Cplx<double> g[9]) {
+#pragma unroll
+    for (int c = 0; c < 9; c++) a.G[a.rowMode ? ((int64_t)c * a.numCols + cid) * Jext + jext : ((int64_t)c * Jext + jext) * a.numCols + cid] = g[c];
+  };
+  Cplx<double> g[9], w[9], t[9];
+#pragma unroll
+  for (int c = 0; c < 9; c++) g[c] = Cplx<double>{c % 4 == 0 ? 1.0 : 0.0, 0.0};
+  const int off = a.sign == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : a.kmax;
+  if (a.sign == MUGIQ_HIP_DISP_SIGN_MINUS) {  // g(-l) = g(-l + 1) U(x_{J - l})^dag
+    for (int l = 1; l <= a.kmax; l++) {
+      load_u(w, (a.J - l % a.J) % a.J);
+      mt_mul3<true>(t, g, w);
+#pragma unroll
+      for (int c = 0; c < 9; c++) g[c] = t[c];
+      store(a.kmax - l, g);
+    }
+#pragma unroll
+    for (int c = 0; c < 9; c++) g[c] = Cplx<double>{c % 4 == 0 ? 1.0 : 0.0, 0.0};
+  }
+  const int last = a.sign == MUGIQ_HIP_DISP_SIGN_PLUS ? a.J + a.kmax : a.J;
+  for (int j = 0; j < last; j++) {
+    store(j + off, g);
+    if (j + 1 < last) {
+      load_u(w, j % a.J);
+      mt_mul3<false>(t, g, w);
+#pragma unroll
+      for (int c = 0; c < 9; c++) g[c] = t[c];
+    }
+  }
+}
+
 // The tile geometry for an entry: the first TJ of {8, 12, 4} that divides the extent and keeps TJ + Kmax within the staged
 // positions of its line count (MUGIQ_HIP_MFMA_TJ = 4 | 8 | 12 fixes it); 0 = none.
 static int mfma_tile_tj(int extent, int kmax, int nSlots = kMT_MaxSlots, bool partitioned = true, bool reduced = false) {
@@ -283,6 +355,38 @@ static int build_axial_gauge_t(void *G_d, const MugiqHipSpinorField &ev, const v
 int build_axial_gauge(void *G_d, const MugiqHipSpinorField &ev, const void *const *E_d, int kmax, int dir, int sign, hipStream_t stream) {
   return ev.precision == 8 ? build_axial_gauge_t<double>(G_d, ev, E_d, kmax, dir, sign, stream)
                            : build_axial_gauge_t<float>(G_d, ev, E_d, kmax, dir, sign, stream);
+}
+
+template <typename F>
+static int build_axial_gauge_links_t(void *G_d, const MugiqHipSpinorField &ev, const MugiqHipGaugeField &U, int kmax, int dir, int sign, hipStream_t stream) {
+  AxialLinkArgs<F> g;
+  g.G = static_cast<Cplx<double> *>(G_d);
+  g.U = static_cast<const Cplx<F> *>(U.data);
+  g.Upo = U.parity_offset;
+  g.Ustride = U.stride;
+  long long strideMu = 1;
+  for (int d = 0; d < 4; d++) {
+    g.X[d] = ev.X[d];
+    g.R[d] = U.R[d];
+    if (d < dir) strideMu *= ev.X[d];
+  }
+  g.dir = dir;
+  g.kmax = kmax;
+  g.sign = sign;
+  g.J = ev.X[dir];
+  g.strideMu = dir == 0 ? 1 : (int)(strideMu / 2);
+  g.H = (int)(ev.volumeCB / ((long long)ev.X[dir] * g.strideMu));
+  g.numCols = 2 * ev.volumeCB / ev.X[dir];
+  g.rowMode = dir == 0;
+  hipLaunchKernelGGL(axial_gauge_from_links_kernel<F>, dim3((g.numCols + 63) / 64), dim3(64), 0, stream, g);
+  MUGIQ_CHECK_HIP(hipGetLastError());
+  return MUGIQ_HIP_SUCCESS;
+}
+// (direction `dir` must not be partitioned: the continued positions are the wrapped sites of the local line)
+int build_axial_gauge_from_links(void *G_d, const MugiqHipSpinorField &ev, const MugiqHipGaugeField &U, int kmax, int dir, int sign, hipStream_t stream) {
+  MUGIQ_REQUIRE(U.precision == ev.precision && U.R[dir] == 0, "axial gauge from the links: gauge precision %d / border %d along %d (internal)", U.precision, U.R[dir], dir);
+  return ev.precision == 8 ? build_axial_gauge_links_t<double>(G_d, ev, U, kmax, dir, sign, stream)
+                           : build_axial_gauge_links_t<float>(G_d, ev, U, kmax, dir, sign, stream);
 }
 
 // ultra_d != NULL: also produce the ultra-local loop (k = 0) into ultra_d as one more slot; *carried says whether that

@@ -561,14 +561,26 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0, int part_sel = 0) 
   if (part && stop > lp->localL[dir]) return entry_stepwise_blocked(lp, id, slot0);
   std::vector<MugiqHipSpinorField> Elocal;
   const bool ahead = part && lp->halo[id].posted;
-  if (!ahead && (st = build_path_links(lp, id, Elocal))) return st;
+  std::vector<int> kv;
+  for (int k = start; k <= stop; k++) kv.push_back(k);
+  // A direction that is not partitioned and an entry the matrix-pipe tile takes: its axial gauge comes straight from the gauge field
+  // (W_1 = U_mu, the continued positions are the wrapped sites) and the path-link fields W_1 .. W_stop are not built at all
+  // (MUGIQ_HIP_GAUGE_FROM_LINKS = 0: build them and the gauge from them, as for the partitioned directions)
+  void *directGauge = nullptr;
+  if (!part && lp->gauge.precision == lp->precision) {
+    bool on = true;
+    if (const char *e = getenv("MUGIQ_HIP_GAUGE_FROM_LINKS")) on = atoi(e) != 0;
+    const size_t gb = on ? axial_gauge_bytes(lp->eVecs[0], dir, kv.data(), (int)kv.size(), 0) : 0;
+    if (gb) {
+      if ((st = scratch_alloc(lp, &directGauge, gb, false))) return st;
+      if ((st = build_axial_gauge_from_links(directGauge, lp->eVecs[0], lp->gauge, stop, dir, sign, lp->stream))) return st;
+    }
+  }
+  if (!ahead && !directGauge && (st = build_path_links(lp, id, Elocal))) return st;
   std::vector<MugiqHipSpinorField> &E = ahead ? lp->halo[id].E : Elocal;
   std::vector<const void *> links;
-  std::vector<int> kv;
-  for (int k = start; k <= stop; k++) {
-    links.push_back(E[k].data);
-    kv.push_back(k);
-  }
+  // (with the gauge at hand the fused call never looks at the link fields: the gauge buffer stands in, and names the hint)
+  for (int k = start; k <= stop; k++) links.push_back(directGauge ? directGauge : E[k].data);
   if (part && lp->halo[id].posted) {
     // the halo of all eigenvectors was posted at the start of the compute: interior tiles, then (once it has landed) the
     // boundary tiles
@@ -613,7 +625,10 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0, int part_sel = 0) 
       if (on) set_axial_gauge_hint(nullptr, nullptr, -1, -1, 0);
     }
   } gaugeScope;
-  if (start > 1) {
+  if (directGauge) {
+    set_axial_gauge_hint(directGauge, links[0], dir, sign, stop);
+    gaugeScope.on = true;
+  } else if (start > 1) {
     const size_t gb = axial_gauge_bytes(lp->eVecs[0], dir, kv.data(), (int)kv.size(), part ? 1 : 0);
     if (gb) {
       void *G = nullptr;

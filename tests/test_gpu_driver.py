@@ -774,7 +774,8 @@ def test_full_size_reflected_entries_agree_with_computed_ones(hip, monkeypatch):
 
 def test_axial_gauge_matrix_pipe_tile_geometries(hip, monkeypatch):
     """csrc/fused_mfma.hip: every tile geometry of the axial-gauge matrix-pipe kernel (4 x 32, 8 x 16, 12 x 16 sites for mu = y, z, t;
-    whole x rows for mu = x), both signs, one to three lengths, with and without the ultra-local loop riding along, against the
+    whole x rows for mu = x), both signs, one to three lengths, with and without the ultra-local loop riding along, the axial gauge
+    straight from the gauge field (default on an unpartitioned lattice) or from path-link fields (MUGIQ_HIP_GAUGE_FROM_LINKS=0), against the
     oracle -- and against the vector tiles of csrc/fused_tile.hip (MUGIQ_HIP_TILE_MFMA=0), which apply W_k per slot instead of
     rotating the eigenvectors into the axial gauge once.  The lattice has a t extent every geometry divides."""
     X, nev = (8, 8, 4, 24), 3
@@ -785,10 +786,10 @@ def test_axial_gauge_matrix_pipe_tile_geometries(hip, monkeypatch):
     ref = orc.compute_loop_position_space(ev, sg, orc.LoopComputeParam(s, a, b), Uo, X)
     monkeypatch.setenv("MUGIQ_HIP_REFLECT", "0")            # every entry from the eigenvectors: both signs go through the kernels
     settings = [{"MUGIQ_HIP_MFMA_TJ": "4"}, {"MUGIQ_HIP_MFMA_TJ": "8"}, {"MUGIQ_HIP_MFMA_TJ": "12"}, {"MUGIQ_HIP_MFMA_ROW": "0"},
-                {"MUGIQ_HIP_CARRY_ULTRALOCAL": "0"}, {"MUGIQ_HIP_TILE_MFMA": "0"}]
+                {"MUGIQ_HIP_CARRY_ULTRALOCAL": "0"}, {"MUGIQ_HIP_GAUGE_FROM_LINKS": "0"}, {"MUGIQ_HIP_TILE_MFMA": "0"}]
     got = {}
     for env in settings:
-        for k in ("MUGIQ_HIP_MFMA_TJ", "MUGIQ_HIP_MFMA_ROW", "MUGIQ_HIP_CARRY_ULTRALOCAL", "MUGIQ_HIP_TILE_MFMA"):
+        for k in ("MUGIQ_HIP_MFMA_TJ", "MUGIQ_HIP_MFMA_ROW", "MUGIQ_HIP_CARRY_ULTRALOCAL", "MUGIQ_HIP_TILE_MFMA", "MUGIQ_HIP_GAUGE_FROM_LINKS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
