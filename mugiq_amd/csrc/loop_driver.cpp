@@ -427,8 +427,17 @@ static int reserve_plan_buffers(MugiqHipLoop *lp) {
   if (anyAhead)
     for (int id = 0; id < lp->nDispEntries; id++)
       if (lp->derivedFrom[id] < 0 && !lp->commDim[lp->dispDir[id]]) {
-        for (int k = 0; k <= lp->dispStop[id]; k++)
-          if ((st = pool_reserve(lp, fieldB))) return st;
+        std::vector<int> kv;
+        for (int k = lp->dispStart[id]; k <= lp->dispStop[id]; k++) kv.push_back(k);
+        bool direct = lp->gauge.precision == lp->precision;
+        if (const char *e = getenv("MUGIQ_HIP_GAUGE_FROM_LINKS")) direct = direct && atoi(e) != 0;
+        const size_t gb = direct ? axial_gauge_bytes(lp->eVecs[0], lp->dispDir[id], kv.data(), (int)kv.size(), 0) : 0;
+        if (gb) {  // (entry_fused: the gauge straight from the gauge field, no link fields)
+          if ((st = pool_reserve(lp, gb))) return st;
+        } else {
+          for (int k = 0; k <= lp->dispStop[id]; k++)
+            if ((st = pool_reserve(lp, fieldB))) return st;
+        }
         break;
       }
   return MUGIQ_HIP_SUCCESS;
