@@ -151,10 +151,13 @@ template <typename F> __global__ __launch_bounds__(64) void axial_gauge_from_lin
   get_coords(c0, base, a.X, p0);  // the j = 0 site of the line (row mode: x = 0 or 1 -- only the other three coordinates are used)
 #pragma unroll
   for (int d = 0; d < 4; d++) XE[d] = a.X[d] + 2 * a.R[d];
-  auto load_u = [&](Cplx<double> u[9], int j) {  // U_mu at position j of the line (0 <= j < J)
+  // U_mu at position j of the line; j < 0 or j >= J: the wrapped site of a periodic line, or -- along a partitioned direction -- the
+  // neighbour's link in the border of the extended field (-R <= j < J + R)
+  auto load_u = [&](Cplx<double> u[9], int j) {
+    const int jj = a.R[a.dir] > 0 ? j : ((j % a.J) + a.J) % a.J;
     int c[4];
 #pragma unroll
-    for (int d = 0; d < 4; d++) c[d] = (d == a.dir ? j : c0[d]) + a.R[d];
+    for (int d = 0; d < 4; d++) c[d] = (d == a.dir ? jj : c0[d]) + a.R[d];
     const int par = p0 ^ (j & 1);  // (borders are even in sum: the extended parity is the interior one)
     const Cplx<F> *q = a.U + (int64_t)par * a.Upo + (int64_t)(a.dir * 9) * a.Ustride + (lex_index(c, XE) >> 1);
 #pragma unroll
@@ -174,7 +177,7 @@ template <typename F> __global__ __launch_bounds__(64) void axial_gauge_from_lin
   const int off = a.sign == MUGIQ_HIP_DISP_SIGN_PLUS ? 0 : a.kmax;
   if (a.sign == MUGIQ_HIP_DISP_SIGN_MINUS) {  // g(-l) = g(-l + 1) U(x_{J - l})^dag
     for (int l = 1; l <= a.kmax; l++) {
-      load_u(w, (a.J - l % a.J) % a.J);
+      load_u(w, -l);
       mt_mul3<true>(t, g, w);
 #pragma unroll
       for (int c = 0; c < 9; c++) g[c] = t[c];
@@ -187,7 +190,7 @@ template <typename F> __global__ __launch_bounds__(64) void axial_gauge_from_lin
   for (int j = 0; j < last; j++) {
     store(j + off, g);
     if (j + 1 < last) {
-      load_u(w, j % a.J);
+      load_u(w, j);
       mt_mul3<false>(t, g, w);
 #pragma unroll
       for (int c = 0; c < 9; c++) g[c] = t[c];
@@ -382,9 +385,18 @@ static int build_axial_gauge_links_t(void *G_d, const MugiqHipSpinorField &ev, c
   MUGIQ_CHECK_HIP(hipGetLastError());
   return MUGIQ_HIP_SUCCESS;
 }
-// (direction `dir` must not be partitioned: the continued positions are the wrapped sites of the local line)
+// Can the gauge of (dir, sign) with lengths up to kmax be taken from the gauge field?  Always along a direction that is not partitioned
+// (border 0: periodic line); along a partitioned one as far as the border of the extended field reaches: the continued positions need the
+// links at J .. J + kmax - 2 (sign +) or -1 .. -kmax (sign -).
+bool axial_gauge_from_links_possible(const MugiqHipSpinorField &ev, const MugiqHipGaugeField &U, int kmax, int dir, int sign) {
+  if (U.precision != ev.precision) return false;
+  if (const char *e = getenv("MUGIQ_HIP_GAUGE_FROM_LINKS"))
+    if (atoi(e) == 0) return false;
+  const int R = U.R[dir];
+  return R == 0 || (sign == MUGIQ_HIP_DISP_SIGN_PLUS ? kmax <= R + 1 : kmax <= R);
+}
 int build_axial_gauge_from_links(void *G_d, const MugiqHipSpinorField &ev, const MugiqHipGaugeField &U, int kmax, int dir, int sign, hipStream_t stream) {
-  MUGIQ_REQUIRE(U.precision == ev.precision && U.R[dir] == 0, "axial gauge from the links: gauge precision %d / border %d along %d (internal)", U.precision, U.R[dir], dir);
+  MUGIQ_REQUIRE(axial_gauge_from_links_possible(ev, U, kmax, dir, sign), "axial gauge from the links: precision %d / border %d along %d, lengths up to %d (internal)", U.precision, U.R[dir], dir, kmax);
   return ev.precision == 8 ? build_axial_gauge_links_t<double>(G_d, ev, U, kmax, dir, sign, stream)
                            : build_axial_gauge_links_t<float>(G_d, ev, U, kmax, dir, sign, stream);
 }

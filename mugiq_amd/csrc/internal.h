@@ -46,7 +46,9 @@ int debug_poison_lds_if_asked(hipStream_t stream);
 // thread, names the W_1 field it was built from, and is cleared with G_d = NULL.
 size_t axial_gauge_bytes(const MugiqHipSpinorField &ev, int dir, const int *kvals, int nK, int partitioned);
 int build_axial_gauge(void *G_d, const MugiqHipSpinorField &ev, const void *const *E_d, int kmax, int dir, int sign, hipStream_t stream);
-// ... straight from the gauge field (a direction that is not partitioned; no path-link fields needed at all)
+// ... straight from the gauge field (no path-link fields needed at all): along a direction that is not partitioned, or as far as the border
+// of the extended field reaches along a partitioned one
+bool axial_gauge_from_links_possible(const MugiqHipSpinorField &ev, const MugiqHipGaugeField &U, int kmax, int dir, int sign);
 int build_axial_gauge_from_links(void *G_d, const MugiqHipSpinorField &ev, const MugiqHipGaugeField &U, int kmax, int dir, int sign, hipStream_t stream);
 void set_axial_gauge_hint(const void *G_d, const void *E1_d, int dir, int sign, int kmax);
 bool axial_gauge_hint_matches(const void *E0_d, int dir, int sign, int kmax);  // E0_d: the first link field of the call

@@ -465,13 +465,20 @@ static int prepare_halo(MugiqHipLoop *lp, int id) {
     MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&h.evPacked, hipEventDisableTiming));
     MUGIQ_CHECK_HIP(hipEventCreateWithFlags(&h.evHalo, hipEventDisableTiming));
   }
-  if ((st = build_path_links(lp, id, h.E))) return st;  // compute stream: the entry's kernels read them there
   {  // the entry is launched once for its interior tiles and once per halo block for its boundary tiles: one gauge for all of them
     std::vector<int> kv;
     for (int k = lp->dispStart[id]; k <= lp->dispStop[id]; k++) kv.push_back(k);
     const size_t gb = axial_gauge_bytes(lp->eVecs[0], lp->dispDir[id], kv.data(), (int)kv.size(), 1);
     h.axialGauge = nullptr;
-    if (gb) {
+    h.E.clear();
+    if (gb && axial_gauge_from_links_possible(lp->eVecs[0], lp->gauge, lp->dispStop[id], lp->dispDir[id], lp->dispSign[id])) {
+      // the neighbour's links of the continued positions are in the border of the extended gauge field: no path-link fields (and
+      // none of their face exchanges) for this entry
+      if ((st = scratch_alloc(lp, &h.axialGauge, gb, false))) return st;
+      if ((st = build_axial_gauge_from_links(h.axialGauge, lp->eVecs[0], lp->gauge, lp->dispStop[id], lp->dispDir[id], lp->dispSign[id], lp->stream))) return st;
+    } else if ((st = build_path_links(lp, id, h.E))) {  // compute stream: the entry's kernels read them there
+      return st;
+    } else if (gb) {
       std::vector<const void *> lk;
       for (int k = 1; k <= lp->dispStop[id]; k++) lk.push_back(h.E[k].data);
       if ((st = scratch_alloc(lp, &h.axialGauge, gb, false))) return st;
@@ -576,10 +583,8 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0, int part_sel = 0) 
   // (W_1 = U_mu, the continued positions are the wrapped sites) and the path-link fields W_1 .. W_stop are not built at all
   // (MUGIQ_HIP_GAUGE_FROM_LINKS = 0: build them and the gauge from them, as for the partitioned directions)
   void *directGauge = nullptr;
-  if (!part && lp->gauge.precision == lp->precision) {
-    bool on = true;
-    if (const char *e = getenv("MUGIQ_HIP_GAUGE_FROM_LINKS")) on = atoi(e) != 0;
-    const size_t gb = on ? axial_gauge_bytes(lp->eVecs[0], dir, kv.data(), (int)kv.size(), 0) : 0;
+  if (!part && axial_gauge_from_links_possible(lp->eVecs[0], lp->gauge, stop, dir, sign)) {
+    const size_t gb = axial_gauge_bytes(lp->eVecs[0], dir, kv.data(), (int)kv.size(), 0);
     if (gb) {
       if ((st = scratch_alloc(lp, &directGauge, gb, false))) return st;
       if ((st = build_axial_gauge_from_links(directGauge, lp->eVecs[0], lp->gauge, stop, dir, sign, lp->stream))) return st;
@@ -589,6 +594,7 @@ static int entry_fused(MugiqHipLoop *lp, int id, void *slot0, int part_sel = 0) 
   std::vector<MugiqHipSpinorField> &E = ahead ? lp->halo[id].E : Elocal;
   std::vector<const void *> links;
   // (with the gauge at hand the fused call never looks at the link fields: the gauge buffer stands in, and names the hint)
+  if (ahead && E.empty()) directGauge = lp->halo[id].axialGauge;  // (prepare_halo took the gauge from the gauge field: no link fields)
   for (int k = start; k <= stop; k++) links.push_back(directGauge ? directGauge : E[k].data);
   if (part && lp->halo[id].posted) {
     // the halo of all eigenvectors was posted at the start of the compute: interior tiles, then (once it has landed) the
