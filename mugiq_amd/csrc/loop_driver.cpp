@@ -409,17 +409,21 @@ static int reserve_plan_buffers(MugiqHipLoop *lp) {
   for (int id = 0; id < lp->nDispEntries; id++) {
     if (!ahead[id]) continue;
     const size_t faceB = (size_t)24 * (lp->volumeCB / lp->localL[lp->dispDir[id]]) * lp->cplxBytes();
-    for (int k = 0; k <= lp->dispStop[id]; k++)
-      if ((st = pool_reserve(lp, fieldB))) return st;  // E_0 .. E_stop, held until the entry has run
-    if ((st = pool_reserve(lp, faceB)) || (st = pool_reserve(lp, faceB))) return st;
-    if ((st = pool_reserve(lp, halo_bytes(lp, id)))) return st;
-    if (!self_neighbour_alias(lp, lp->dispDir[id]) && (st = pool_reserve(lp, halo_bytes(lp, id)))) return st;
+    size_t gb = 0;
     {  // the entry's axial gauge (csrc/fused_mfma.hip), where that tile takes the entry
       std::vector<int> kv;
       for (int k = lp->dispStart[id]; k <= lp->dispStop[id]; k++) kv.push_back(k);
-      const size_t gb = axial_gauge_bytes(lp->eVecs[0], lp->dispDir[id], kv.data(), (int)kv.size(), 1);
-      if (gb && (st = pool_reserve(lp, gb))) return st;
+      gb = axial_gauge_bytes(lp->eVecs[0], lp->dispDir[id], kv.data(), (int)kv.size(), 1);
     }
+    if (!(gb && axial_gauge_from_links_possible(lp->eVecs[0], lp->gauge, lp->dispStop[id], lp->dispDir[id], lp->dispSign[id]))) {
+      // (prepare_halo: the gauge from the extended gauge field where its border reaches far enough -- then no link fields)
+      for (int k = 0; k <= lp->dispStop[id]; k++)
+        if ((st = pool_reserve(lp, fieldB))) return st;  // E_0 .. E_stop, held until the entry has run
+      if ((st = pool_reserve(lp, faceB)) || (st = pool_reserve(lp, faceB))) return st;
+    }
+    if ((st = pool_reserve(lp, halo_bytes(lp, id)))) return st;
+    if (!self_neighbour_alias(lp, lp->dispDir[id]) && (st = pool_reserve(lp, halo_bytes(lp, id)))) return st;
+    if (gb && (st = pool_reserve(lp, gb))) return st;
     anyAhead = true;
   }
   // the entry that runs before the halos are posted keeps its link fields out of the pool until the compute ends (see
@@ -429,8 +433,7 @@ static int reserve_plan_buffers(MugiqHipLoop *lp) {
       if (lp->derivedFrom[id] < 0 && !lp->commDim[lp->dispDir[id]]) {
         std::vector<int> kv;
         for (int k = lp->dispStart[id]; k <= lp->dispStop[id]; k++) kv.push_back(k);
-        bool direct = lp->gauge.precision == lp->precision;
-        if (const char *e = getenv("MUGIQ_HIP_GAUGE_FROM_LINKS")) direct = direct && atoi(e) != 0;
+        const bool direct = axial_gauge_from_links_possible(lp->eVecs[0], lp->gauge, lp->dispStop[id], lp->dispDir[id], lp->dispSign[id]);
         const size_t gb = direct ? axial_gauge_bytes(lp->eVecs[0], lp->dispDir[id], kv.data(), (int)kv.size(), 0) : 0;
         if (gb) {  // (entry_fused: the gauge straight from the gauge field, no link fields)
           if ((st = pool_reserve(lp, gb))) return st;
